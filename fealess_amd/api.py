@@ -1,0 +1,255 @@
+"""Host-side Python mirror of the reference's operator surface, on top of the C ABI.
+
+This is harness code (tests, bench.py); the product is libfealess_hip.so and the C++ adapter in
+fealess_amd/cadreco.  Names follow the reference: Detector.match (linemod.cpp:1356),
+quantized_orientations (:230), quantized_normals (:595), depth_to_3d (depth_to_3d.cpp:190),
+icp_cloud_to_cloud_ex (ICP.cpp:617), detection (detection.cpp:11), Recognizer.recognition
+(obj_reco_lmicp.cpp:86).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib as L
+from .bank import MATCH_DTYPE, TemplateBank
+
+
+class FealessError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fealess_hip error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.fl_context_create(device, C.byref(h))
+        if rc != L.FL_OK:
+            raise FealessError(rc, "fl_context_create failed (no HIP device? there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != L.FL_OK:
+            raise FealessError(rc, self.lib.fl_last_error(self.h).decode(errors="replace"))
+
+    def set_stream(self, stream_handle):
+        self.check(self.lib.fl_context_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self.check(self.lib.fl_context_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.fl_context_destroy(self.h)
+            self.h = None
+
+    # ---- stage entry points (host numpy arrays in/out) ----
+    def quantized_orientations(self, bgr, weak_threshold=10.0):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        out = np.empty((h, w), np.uint8)
+        self.check(self.lib.fl_quantized_orientations(self.h, _ptr(bgr), w, h, weak_threshold, _ptr(out), L.FL_MEM_HOST))
+        return out
+
+    def quantized_normals(self, depth, distance_threshold=2000, difference_threshold=50):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        h, w = depth.shape
+        out = np.empty((h, w), np.uint8)
+        self.check(self.lib.fl_quantized_normals(self.h, _ptr(depth), w, h, distance_threshold, difference_threshold,
+                                                 _ptr(out), L.FL_MEM_HOST))
+        return out
+
+    def pyrdown_bgr(self, bgr):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w = bgr.shape[:2]
+        out = np.empty((h // 2, w // 2, 3), np.uint8)
+        self.check(self.lib.fl_pyrdown_bgr(self.h, _ptr(bgr), w, h, _ptr(out), L.FL_MEM_HOST))
+        return out
+
+    def build_linear_memories(self, quantized, T):
+        q = np.ascontiguousarray(quantized, np.uint8)
+        h, w = q.shape
+        stride = self.lib.fl_lm_label_stride(w, h, T)
+        out = np.empty(8 * stride, np.uint8)
+        self.check(self.lib.fl_build_linear_memories(self.h, _ptr(q), w, h, T, _ptr(out), L.FL_MEM_HOST))
+        return out.reshape(8, stride)
+
+    def depth_to_3d(self, depth, fx, fy, cx, cy):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        h, w = depth.shape
+        out = np.empty((h, w, 3), np.float32)
+        self.check(self.lib.fl_depth_to_3d(self.h, _ptr(depth), w, h, fx, fy, cx, cy, _ptr(out), L.FL_MEM_HOST))
+        return out
+
+    def icp_cloud_to_cloud_ex(self, ref, model, icp_it_thr=4, dist_mean_thr=0.0, dist_diff_thr=0.0,
+                              mode=L.FL_ICP_PARITY):
+        ref = np.ascontiguousarray(ref, np.float32).reshape(-1, 3)
+        model = np.ascontiguousarray(model, np.float32).reshape(-1, 3)
+        res = L.IcpResult()
+        self.check(self.lib.fl_icp(self.h, _ptr(ref), len(ref), _ptr(model), len(model), icp_it_thr, dist_mean_thr,
+                                   dist_diff_thr, mode, L.FL_MEM_HOST, C.byref(res)))
+        return icp_result_to_dict(res)
+
+    def detection(self, model_depth_mm, scene_depth_mm, K, rect_model, rect_ref, icp_it_thr, dist_mean_thr,
+                  dist_diff_thr, r_match, t_match, mode=L.FL_ICP_PARITY):
+        md = np.ascontiguousarray(model_depth_mm, np.uint16)
+        sd = np.ascontiguousarray(scene_depth_mm, np.uint16)
+        h, w = sd.shape
+        k = L.Intrinsics(w, h, *K)
+        rm = (C.c_int * 4)(*[int(v) for v in rect_model])
+        rr = (C.c_int * 4)(*[int(v) for v in rect_ref])
+        rmat = (C.c_float * 9)(*np.asarray(r_match, np.float32).ravel())
+        tvec = (C.c_float * 3)(*np.asarray(t_match, np.float32).ravel())
+        res = L.DetectionResult()
+        self.check(self.lib.fl_detection(self.h, _ptr(md), _ptr(sd), w, h, C.byref(k), rm, rr, icp_it_thr, dist_mean_thr,
+                                         dist_diff_thr, rmat, tvec, mode, L.FL_MEM_HOST, C.byref(res)))
+        return detection_result_to_dict(res)
+
+
+def icp_result_to_dict(r):
+    return dict(R=np.array(r.R, np.float32).reshape(3, 3), T=np.array(r.T, np.float32), dist_mean=np.float32(r.dist_mean),
+                px_ratio=np.float32(r.px_ratio), iters=int(r.iters), n_corr_last=int(r.n_corr_last))
+
+
+def detection_result_to_dict(r):
+    return dict(R_final=np.array(r.R_final, np.float32).reshape(3, 3), T_final=np.array(r.T_final, np.float32),
+                icp=icp_result_to_dict(r.icp), n_points=int(r.n_points), status=int(r.status))
+
+
+def recognition_result_to_dict(r):
+    return dict(status=int(r.status), found=int(r.found), n_matches=int(r.n_matches),
+                best=dict(x=r.best.x, y=r.best.y, similarity=np.float32(r.best.similarity), class_idx=r.best.class_idx,
+                          template_id=r.best.template_id),
+                pose=np.array(r.pose, np.float32).reshape(4, 4), det=detection_result_to_dict(r.det))
+
+
+class Detector:
+    """cup_linemod::Detector resident on one GPU (linemod.hpp:292-412)."""
+
+    def __init__(self, ctx, modalities, T_pyramid):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.M = modalities
+        self.T = list(T_pyramid)
+        self.L = len(self.T)
+        h = C.c_void_p()
+        arr = (C.c_int * self.L)(*self.T)
+        ctx.check(self.lib.fl_detector_create(ctx.h, modalities, self.L, arr, C.byref(h)))
+        self.h = h
+        self.banks = []
+        self.w0 = self.h0 = 0
+
+    def add_class(self, bank: TemplateBank):
+        assert bank.levels == self.L and bank.modalities == self.M
+        t, f, p = bank.arrays()
+        self.ctx.check(self.lib.fl_detector_add_class(self.h, bank.class_id.encode(), bank.n_pyramids, _ptr(t), _ptr(f),
+                                                      len(f), _ptr(p) if len(p) else None))
+        self.banks.append(bank)
+        self.banks.sort(key=lambda b: b.class_id)
+
+    def finalize(self, w0, h0, max_batch=1, max_candidates=0):
+        # model depth renders first (class order = sorted class ids)
+        for ci, b in enumerate(self.banks):
+            if b.model_depths and len(b.model_depths) == b.n_pyramids:
+                d = np.ascontiguousarray(np.stack(b.model_depths), np.uint16)
+                self.ctx.check(self.lib.fl_detector_set_model_depths(self.h, ci, 0, b.n_pyramids, _ptr(d), d.shape[2],
+                                                                     d.shape[1], L.FL_MEM_HOST))
+        self.ctx.check(self.lib.fl_detector_finalize(self.h, w0, h0, max_batch, max_candidates))
+        self.w0, self.h0, self.max_batch = w0, h0, max_batch
+
+    def num_templates(self):
+        return self.lib.fl_detector_num_templates(self.h)
+
+    def match_quantized(self, quantized, threshold, cap=65536):
+        """quantized: list [l*M+m] of (h_l, w_l) uint8 arrays (the pass-through modality)."""
+        qs = [np.ascontiguousarray(q, np.uint8) for q in quantized]
+        ptrs = (C.c_void_p * len(qs))(*[q.ctypes.data for q in qs])
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_int(0)
+        self.ctx.check(self.lib.fl_match_quantized(self.h, ptrs, L.FL_MEM_HOST, threshold, _ptr(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)], n.value
+
+    def match(self, bgr, depth, threshold, cap=65536):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16) if depth is not None else None
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_int(0)
+        self.ctx.check(self.lib.fl_match_frame(self.h, _ptr(bgr), _ptr(depth) if depth is not None else None,
+                                               L.FL_MEM_HOST, threshold, _ptr(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)], n.value
+
+    def similarity_maps(self, first, count):
+        g = self.T[-1]
+        w, h = self.w0 >> (self.L - 1), self.h0 >> (self.L - 1)
+        W, H = w // g, h // g
+        out = np.zeros((count, H, W), np.uint16)
+        self.ctx.check(self.lib.fl_similarity_maps(self.h, first, count, _ptr(out)))
+        return out
+
+    def last_quantized(self):
+        sizes = [((self.h0 >> l), (self.w0 >> l)) for l in range(self.L) for _ in range(self.M)]
+        buf = np.zeros(sum(a * b for a, b in sizes), np.uint8)
+        self.ctx.check(self.lib.fl_last_quantized(self.h, _ptr(buf)))
+        out, o = [], 0
+        for a, b in sizes:
+            out.append(buf[o:o + a * b].reshape(a, b).copy())
+            o += a * b
+        return out
+
+    def _params(self, threshold, icp_it_thr, dist_mean_thr, dist_diff_thr, mode):
+        return L.RecognitionParams(threshold, icp_it_thr, dist_mean_thr, dist_diff_thr, mode)
+
+    def recognize_batch(self, bgrs, depths, K, threshold=75.0, icp_it_thr=10, dist_mean_thr=0.5, dist_diff_thr=0.01,
+                        mode=L.FL_ICP_PARITY):
+        """Host arrays in, list of result dicts out (CObjRecoLmICP::Recognition per frame)."""
+        n = len(bgrs)
+        bs = [np.ascontiguousarray(b, np.uint8) for b in bgrs]
+        ds = [np.ascontiguousarray(d, np.uint16) for d in depths]
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        dp = (C.c_void_p * n)(*[d.ctypes.data for d in ds])
+        k = L.Intrinsics(self.w0, self.h0, *K)
+        p = self._params(threshold, icp_it_thr, dist_mean_thr, dist_diff_thr, mode)
+        res = (L.RecognitionResult * n)()
+        self.ctx.check(self.lib.fl_recognize_batch(self.h, n, bp, dp, L.FL_MEM_HOST, C.byref(k), C.byref(p), res))
+        return [recognition_result_to_dict(r) for r in res]
+
+    def recognize_submit_device(self, bgr_ptrs, depth_ptrs, K, params):
+        n = len(bgr_ptrs)
+        bp = (C.c_void_p * n)(*bgr_ptrs)
+        dp = (C.c_void_p * n)(*depth_ptrs)
+        k = L.Intrinsics(self.w0, self.h0, *K)
+        self.ctx.check(self.lib.fl_recognize_submit(self.h, n, bp, dp, L.FL_MEM_DEVICE, C.byref(k), C.byref(params)))
+
+    def recognize_collect(self, n):
+        res = (L.RecognitionResult * n)()
+        self.ctx.check(self.lib.fl_recognize_collect(self.h, n, res))
+        return res
+
+    def stage_times(self):
+        t = L.StageTimes()
+        self.ctx.check(self.lib.fl_last_stage_times(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.StageTimes._fields_}
+
+    def export_topk(self, frame, k, template_id_base, dev_ptr):
+        self.ctx.check(self.lib.fl_export_topk(self.h, frame, k, template_id_base, C.c_void_p(dev_ptr)))
+
+    def close(self):
+        if self.h:
+            self.lib.fl_detector_destroy(self.h)
+            self.h = None
+
+
+def merge_topk(records, cap):
+    """Host merge of all-gathered top-k records (fl_merge_topk): numpy MATCH_DTYPE in/out."""
+    lib = L.load()
+    rec = np.ascontiguousarray(records, MATCH_DTYPE)
+    out = np.zeros(cap, MATCH_DTYPE)
+    n = lib.fl_merge_topk(_ptr(rec), len(rec), _ptr(out), cap)
+    if n < 0:
+        raise FealessError(n, "fl_merge_topk")
+    return out[:n]

@@ -1,0 +1,475 @@
+// fl_frontend.hip -- gfx950 kernels for the quantisation front-end of cup_linemod
+// (reference: linemod/linemod.cpp:230-385 quantizedOrientations + hysteresisGradient,
+//  :434-453 ColorGradientPyramid::pyrDown, :567-685 quantizedNormals, :721-739 NN downsample).
+//
+//   k_color_quantize   GaussianBlur 7x7 -> Sobel x/y -> max-magnitude channel -> fastAtan2 ->
+//                      16-bin quantise -> 3x3 majority vote, fused through LDS tiles: the BGR
+//                      tile is read from HBM once and only the one-hot byte image is written.
+//   k_pyrdown_bgr      cv::pyrDown [1 4 6 4 1]^2, (acc+128)>>8, REFLECT_101
+//   k_normals          bilateral 8-neighbour LSQ normal (int64) + NORMAL_LUT
+//   k_median5          exact 5x5 median of one-hot bytes (replicated border)
+//   k_resize_nn_half   src(2y, 2x)
+//
+// The integer stages are exact; the float stages restate OpenCV 3.x's arithmetic operator by
+// operator (built with -ffp-contract=off; IEEE divide/sqrt are hipcc's default), so they equal
+// oracle/frontend_oracle.c bit for bit.  OpenCV itself is not available to compare with:
+// "parity unpinned" at this boundary.
+#include "fl_internal.h"
+#include <float.h>
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+
+// cv::fastAtan2 in degrees (OpenCV 3.x hal::fastAtan32f), used by cv::phase (linemod.cpp:303)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------
+#define CQ_TW 32
+#define CQ_TH 16
+#define CQ_SW (CQ_TW + 10)   // source tile: +-5
+#define CQ_SH (CQ_TH + 10)
+#define CQ_MW (CQ_TW + 4)    // smoothed tile: +-2
+#define CQ_MH (CQ_TH + 4)
+#define CQ_QW (CQ_TW + 2)    // quantised tile: +-1
+#define CQ_QH (CQ_TH + 2)
+
+__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restrict__ bgr, size_t in_stride,
+                                                        uint8_t *__restrict__ dst, size_t out_stride, int w, int h,
+                                                        float threshold_sq)
+{
+  __shared__ uint8_t s_src[CQ_SH][CQ_SW][3];
+  __shared__ uint16_t s_row[CQ_SH][CQ_MW][3];    // horizontal pass, 8 fractional bits (<= 65280)
+  __shared__ uint8_t s_sm[CQ_MH][CQ_MW][3];
+  __shared__ uint8_t s_q[CQ_QH][CQ_QW];
+  __shared__ float s_mag[CQ_TH][CQ_TW];
+  const uint8_t *src = bgr + (size_t)blockIdx.z * in_stride;
+  uint8_t *out = dst + (size_t)blockIdx.z * out_stride;
+  const int x0 = blockIdx.x * CQ_TW, y0 = blockIdx.y * CQ_TH;
+  const int tid = threadIdx.x;
+  // LDS slot (r, c) of s_src holds image pixel (clamp(y0-5+r), clamp(x0-5+c))
+  for (int i = tid; i < CQ_SH * CQ_SW; i += 256) {
+    const int r = i / CQ_SW, c = i - r * CQ_SW;
+    const int yy = clampi(y0 - 5 + r, 0, h - 1), xx = clampi(x0 - 5 + c, 0, w - 1);
+    const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
+    s_src[r][c][0] = p[0];
+    s_src[r][c][1] = p[1];
+    s_src[r][c][2] = p[2];
+  }
+  __syncthreads();
+  // GaussianBlur 7x7, sigma 0 -> {8,28,56,72,56,28,8}/256 per pass, BORDER_REPLICATE (linemod.cpp:247).
+  // A smoothed sample requested outside the image is the smoothed sample at the clamped
+  // position (that is what Sobel's own BORDER_REPLICATE reads), hence the clamps on the centre.
+  for (int i = tid; i < CQ_SH * CQ_MW; i += 256) {
+    const int r = i / CQ_MW, c = i - r * CQ_MW;
+    const int xc = clampi(x0 - 2 + c, 0, w - 1);
+    int acc0 = 0, acc1 = 0, acc2 = 0;
+    const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int cc = clampi(xc + t - 3, 0, w - 1) - (x0 - 5);
+      acc0 += kk[t] * s_src[r][cc][0];
+      acc1 += kk[t] * s_src[r][cc][1];
+      acc2 += kk[t] * s_src[r][cc][2];
+    }
+    s_row[r][c][0] = (uint16_t)acc0;
+    s_row[r][c][1] = (uint16_t)acc1;
+    s_row[r][c][2] = (uint16_t)acc2;
+  }
+  __syncthreads();
+  for (int i = tid; i < CQ_MH * CQ_MW; i += 256) {
+    const int r = i / CQ_MW, c = i - r * CQ_MW;
+    const int yc = clampi(y0 - 2 + r, 0, h - 1);
+    int acc0 = 0, acc1 = 0, acc2 = 0;
+    const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int rr = clampi(yc + t - 3, 0, h - 1) - (y0 - 5);
+      acc0 += kk[t] * s_row[rr][c][0];
+      acc1 += kk[t] * s_row[rr][c][1];
+      acc2 += kk[t] * s_row[rr][c][2];
+    }
+    s_sm[r][c][0] = (uint8_t)((acc0 + (1 << 15)) >> 16);
+    s_sm[r][c][1] = (uint8_t)((acc1 + (1 << 15)) >> 16);
+    s_sm[r][c][2] = (uint8_t)((acc2 + (1 << 15)) >> 16);
+  }
+  __syncthreads();
+  // Sobel 3x3 -> strongest channel -> phase -> 16 bins (:248-303, :314); quantised tile +-1
+  for (int i = tid; i < CQ_QH * CQ_QW; i += 256) {
+    const int r = i / CQ_QW, c = i - r * CQ_QW;
+    const int y = y0 - 1 + r, x = x0 - 1 + c;
+    uint8_t q = 0;
+    if (y >= 0 && y < h && x >= 0 && x < w) {
+      const int mr = r + 1, mc = c + 1;         // same pixel in s_sm coordinates
+      int bdx = 0, bdy = 0, bmag = 0;
+      int dxs[3], dys[3], mags[3];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+#define SM(rr, cc) ((int)s_sm[rr][cc][ch])
+        const int dx = (SM(mr - 1, mc + 1) - SM(mr - 1, mc - 1)) + 2 * (SM(mr, mc + 1) - SM(mr, mc - 1)) +
+                       (SM(mr + 1, mc + 1) - SM(mr + 1, mc - 1));
+        const int dy = (SM(mr + 1, mc - 1) - SM(mr - 1, mc - 1)) + 2 * (SM(mr + 1, mc) - SM(mr - 1, mc)) +
+                       (SM(mr + 1, mc + 1) - SM(mr - 1, mc + 1));
+#undef SM
+        dxs[ch] = dx;
+        dys[ch] = dy;
+        mags[ch] = dx * dx + dy * dy;
+      }
+      if (mags[0] >= mags[1] && mags[0] >= mags[2]) { bdx = dxs[0]; bdy = dys[0]; bmag = mags[0]; }
+      else if (mags[1] >= mags[0] && mags[1] >= mags[2]) { bdx = dxs[1]; bdy = dys[1]; bmag = mags[1]; }
+      else { bdx = dxs[2]; bdy = dys[2]; bmag = mags[2]; }
+      if (r >= 1 && r <= CQ_TH && c >= 1 && c <= CQ_TW) s_mag[r - 1][c - 1] = (float)bmag;
+      const float ang = fast_atan2_deg((float)bdy, (float)bdx);
+      const float v = ang * (float)(16.0 / 360.0);
+      int qi = __float2int_rn(v);                        // cvRound: round half to even
+      qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
+      // hysteresisGradient :316-335: border rows/cols zeroed, interior folded to 8 bins
+      q = (y == 0 || y == h - 1 || x == 0 || x == w - 1) ? 0 : (uint8_t)(qi & 7);
+    }
+    s_q[r][c] = q;
+  }
+  __syncthreads();
+  // 3x3 majority vote (:337-384)
+  for (int i = tid; i < CQ_TH * CQ_TW; i += 256) {
+    const int r = i / CQ_TW, c = i - r * CQ_TW;
+    const int y = y0 + r, x = x0 + c;
+    if (y >= h || x >= w) continue;
+    uint8_t res = 0;
+    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1 && s_mag[r][c] > threshold_sq) {
+      unsigned hist = 0;                                 // 8 x 4-bit counters
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) hist += 1u << (4 * s_q[r + dy][c + dx]);
+      int max_votes = 0, index = -1;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int v = (hist >> (4 * b)) & 15;
+        if (max_votes < v) { index = b; max_votes = v; }
+      }
+      if (max_votes >= 5) res = (uint8_t)(1 << index);
+    }
+    out[(size_t)y * w + x] = res;
+  }
+}
+
+int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst,
+                                     size_t out_stride, int n_frames, int w, int h, float weak_threshold)
+{
+  dim3 grid((w + CQ_TW - 1) / CQ_TW, (h + CQ_TH - 1) / CQ_TH, n_frames);
+  hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, ctx->stream, bgr, in_stride, dst, out_stride, w, h,
+                     weak_threshold * weak_threshold);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyrdown_bgr(const uint8_t *__restrict__ src_, size_t in_stride,
+                                                     uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+{
+  const int dw = w / 2, dh = h / 2;
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= dw || y >= dh) return;
+  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  const int k[5] = {1, 4, 6, 4, 1};
+  int acc0 = 0, acc1 = 0, acc2 = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int yy = reflect101(2 * y + j - 2, h);
+    int r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int xx = reflect101(2 * x + i - 2, w);
+      const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
+      r0 += k[i] * p[0];
+      r1 += k[i] * p[1];
+      r2 += k[i] * p[2];
+    }
+    acc0 += k[j] * r0;
+    acc1 += k[j] * r1;
+    acc2 += k[j] * r2;
+  }
+  uint8_t *o = dst + ((size_t)y * dw + x) * 3;
+  o[0] = (uint8_t)((acc0 + 128) >> 8);
+  o[1] = (uint8_t)((acc1 + 128) >> 8);
+  o[2] = (uint8_t)((acc2 + 128) >> 8);
+}
+
+int fl_launch_pyrdown_bgr(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst, size_t out_stride,
+                          int n_frames, int w, int h)
+{
+  dim3 grid((w / 2 + 31) / 32, (h / 2 + 7) / 8, n_frames);
+  hipLaunchKernelGGL(k_pyrdown_bgr, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// NORMAL_LUT[20][20][20] (linemod/normal_lut.i): independent of its first index; entry [y][x]
+// is 1 << k with k the first of the 8 directions k*45deg maximising (x-10)cos + (y-10)sin.
+// The 400 distinct bytes are generated on the host by the same rule as oracle/frontend_oracle.c
+// and uploaded once.
+__constant__ uint8_t c_normal_lut[400];
+static bool g_normal_lut_ready[64] = {false};
+
+static int ensure_normal_lut(fl_context *ctx)
+{
+  if (ctx->device < 64 && g_normal_lut_ready[ctx->device]) return FL_OK;
+  uint8_t lut[400];
+  for (int y = 0; y < 20; ++y)
+    for (int x = 0; x < 20; ++x) {
+      double best = -1e300;
+      int bk = 0;
+      for (int k = 0; k < 8; ++k) {
+        double a = k * (3.14159265358979323846 / 4);
+        double d = (x - 10) * cos(a) + (y - 10) * sin(a);
+        if (d > best + 1e-9) { best = d; bk = k; }
+      }
+      lut[y * 20 + x] = (uint8_t)(1 << bk);
+    }
+  FL_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_normal_lut), lut, sizeof(lut)));
+  if (ctx->device < 64) g_normal_lut_ready[ctx->device] = true;
+  return FL_OK;
+}
+
+__device__ __forceinline__ void accum_bilateral(long long delta, long long i, long long j, long long *A, long long *b,
+                                                int threshold)
+{
+  const long long f = (delta < 0 ? -delta : delta) < threshold ? 1 : 0;     // linemod.cpp:569
+  const long long fi = f * i, fj = f * j;
+  A[0] += fi * i;
+  A[1] += fi * j;
+  A[3] += fj * j;
+  b[0] += fi * delta;
+  b[1] += fj * delta;
+}
+
+__global__ __launch_bounds__(256) void k_normals(const uint16_t *__restrict__ depth_, size_t in_stride,
+                                                 uint8_t *__restrict__ dst_, size_t out_stride, int w, int h,
+                                                 int distance_threshold, int difference_threshold)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const uint16_t *depth = depth_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  const int r = 5;
+  uint8_t out = 0;
+  if (y >= r && y < h - r - 1 && x >= r && x < w - r - 1) {               // loop bounds :619, :624
+    const uint16_t *p = depth + (size_t)y * w + x;
+    const long long d = p[0];
+    if (d < distance_threshold) {
+      long long A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
+      accum_bilateral((long long)p[-r - r * w] - d, -r, -r, A, b, difference_threshold);
+      accum_bilateral((long long)p[0 - r * w] - d, 0, -r, A, b, difference_threshold);
+      accum_bilateral((long long)p[+r - r * w] - d, +r, -r, A, b, difference_threshold);
+      accum_bilateral((long long)p[-r] - d, -r, 0, A, b, difference_threshold);
+      accum_bilateral((long long)p[+r] - d, +r, 0, A, b, difference_threshold);
+      accum_bilateral((long long)p[-r + r * w] - d, -r, +r, A, b, difference_threshold);
+      accum_bilateral((long long)p[0 + r * w] - d, 0, +r, A, b, difference_threshold);
+      accum_bilateral((long long)p[+r + r * w] - d, +r, +r, A, b, difference_threshold);
+      const long long det = A[0] * A[3] - A[1] * A[1];
+      const long long ddx = A[3] * b[0] - A[1] * b[1];
+      const long long ddy = -A[1] * b[0] + A[0] * b[1];
+      float nx = (float)(617 * ddx);
+      float ny = (float)(617 * ddy);
+      float nz = (float)(-det * d);
+      const float s = sqrtf(nx * nx + ny * ny + nz * nz);
+      if (s > 0) {
+        const float inv = 1.0f / s;
+        nx *= inv;
+        ny *= inv;
+        nz *= inv;
+        const int v1 = (int)(nx * 10 + 10);
+        const int v2 = (int)(ny * 10 + 10);
+        const int v3 = (int)(nz * 20 + 20);
+        // Q7: v3 == 20 is an out-of-bounds read in the reference; defined as 0 here
+        if (v1 >= 0 && v1 <= 19 && v2 >= 0 && v2 <= 19 && v3 >= 0 && v3 <= 19) out = c_normal_lut[v2 * 20 + v1];
+      }
+    }
+  }
+  dst[(size_t)y * w + x] = out;
+}
+
+// exact median of 25 bytes that are 0 or one-hot: nine 5-bit counters packed in a 64-bit word
+__global__ __launch_bounds__(256) void k_median5(const uint8_t *__restrict__ src_, size_t in_stride,
+                                                 uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  unsigned long long cnt = 0;
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const uint8_t *row = src + (size_t)clampi(y + dy, 0, h - 1) * w;
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const unsigned v = row[clampi(x + dx, 0, w - 1)];
+      const int idx = v ? (32 - __clz(v)) : 0;          // 0 -> 0, 1<<k -> k+1 (ascending in value)
+      cnt += 1ull << (5 * idx);
+    }
+  }
+  int acc = 0, idx = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    acc += (int)((cnt >> (5 * i)) & 31);
+    if (acc >= 13) { idx = i; break; }
+  }
+  dst[(size_t)y * w + x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
+}
+
+int fl_launch_quantized_normals(fl_context *ctx, const uint16_t *depth, size_t in_stride, uint8_t *dst,
+                                size_t out_stride, uint8_t *tmp, size_t tmp_stride, int n_frames, int w, int h,
+                                int distance_threshold, int difference_threshold)
+{
+  int rc = ensure_normal_lut(ctx);
+  if (rc) return rc;
+  dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, ctx->stream, depth, in_stride / sizeof(uint16_t), tmp, tmp_stride, w,
+                     h, distance_threshold, difference_threshold);
+  FL_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, ctx->stream, (const uint8_t *)tmp, tmp_stride, dst, out_stride, w, h);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+__global__ __launch_bounds__(256) void k_resize_nn_half(const uint8_t *__restrict__ src_, size_t in_stride,
+                                                        uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+{
+  const int dw = w / 2, dh = h / 2;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  // cv::resize INTER_NEAREST (linemod.cpp:731): sx = min(floor(x * (1 / (dw / w))), w - 1)
+  int sx = (int)floor(x * (1.0 / ((double)dw / w))), sy = (int)floor(y * (1.0 / ((double)dh / h)));
+  sx = min(sx, w - 1);
+  sy = min(sy, h - 1);
+  dst[(size_t)y * dw + x] = src[(size_t)sy * w + sx];
+}
+
+int fl_launch_resize_nn_half(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst, size_t out_stride,
+                             int n_frames, int w, int h)
+{
+  dim3 grid((w / 2 + 63) / 64, (h / 2 + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_resize_nn_half, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Modality::process + pyrDown + quantize for every level (linemod.cpp:1369-1416) of n_frames frames
+// resident in the detector workspace.  Default modality parameters (linemod.cpp:515-519, 827-832).
+int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_t bgr_stride, const uint16_t *depth,
+                       size_t depth_stride)
+{
+  fl_context *ctx = det->ctx;
+  int rc;
+  for (int l = 0; l < det->L; ++l) {
+    const FlLevelGeom &g = det->geom[l];
+    if (l > 0) {
+      const FlLevelGeom &p = det->geom[l - 1];
+      rc = fl_launch_pyrdown_bgr(ctx, l == 1 ? bgr : det->d_ws + p.bgr_off, l == 1 ? bgr_stride : det->ws_stride,
+                                 det->d_ws + g.bgr_off, det->ws_stride, n_frames, p.w, p.h);
+      if (rc) return rc;
+      if (det->M > 1) {
+        rc = fl_launch_resize_nn_half(ctx, det->d_ws + p.quant_off[1], det->ws_stride, det->d_ws + g.quant_off[1],
+                                      det->ws_stride, n_frames, p.w, p.h);
+        if (rc) return rc;
+      }
+    } else if (det->M > 1) {
+      rc = fl_launch_quantized_normals(ctx, depth, depth_stride,
+                                       det->d_ws + g.quant_off[1], det->ws_stride, det->d_ws + det->off_tmp,
+                                       det->ws_stride, n_frames, g.w, g.h, 2000, 50);
+      if (rc) return rc;
+    }
+    rc = fl_launch_quantized_orientations(ctx, l == 0 ? bgr : det->d_ws + g.bgr_off, l == 0 ? bgr_stride : det->ws_stride,
+                                          det->d_ws + g.quant_off[0], det->ws_stride, n_frames, g.w, g.h, 10.0f);
+    if (rc) return rc;
+  }
+  if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[1], ctx->stream));
+  return FL_OK;
+}
+
+// ---- single-image stage entry points ----------------------------------------------------------
+template <typename F>
+static int run_stage(fl_context *ctx, const void *in, size_t in_bytes, void *out, size_t out_bytes, size_t tmp_bytes,
+                     int mem, F body)
+{
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const uint8_t *din = (const uint8_t *)in;
+  uint8_t *dout = (uint8_t *)out, *dtmp = nullptr;
+  void *s = nullptr;
+  size_t need = fl_align(tmp_bytes, 256) + (mem == FL_MEM_HOST ? fl_align(in_bytes, 256) + fl_align(out_bytes, 256) : 0);
+  if (need) {
+    int rc = fl_scratch(ctx, need, &s);
+    if (rc) return rc;
+  }
+  dtmp = (uint8_t *)s;
+  if (mem == FL_MEM_HOST) {
+    uint8_t *b = (uint8_t *)s + fl_align(tmp_bytes, 256);
+    FL_HIP(ctx, hipMemcpyAsync(b, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    din = b;
+    dout = b + fl_align(in_bytes, 256);
+  }
+  int rc = body(din, dout, dtmp);
+  if (rc) return rc;
+  if (mem == FL_MEM_HOST) {
+    FL_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return FL_OK;
+}
+
+extern "C" int fl_quantized_orientations(fl_context *ctx, const uint8_t *bgr, int w, int h, float weak_threshold,
+                                         uint8_t *dst, int mem)
+{
+  if (!ctx || !bgr || !dst || w < 3 || h < 3) return FL_ERR_INVALID;
+  return run_stage(ctx, bgr, (size_t)w * h * 3, dst, (size_t)w * h, 0, mem,
+                   [&](const uint8_t *i, uint8_t *o, uint8_t *) {
+                     return fl_launch_quantized_orientations(ctx, i, 0, o, 0, 1, w, h, weak_threshold);
+                   });
+}
+
+extern "C" int fl_quantized_normals(fl_context *ctx, const uint16_t *depth, int w, int h, int distance_threshold,
+                                    int difference_threshold, uint8_t *dst, int mem)
+{
+  if (!ctx || !depth || !dst || w <= 0 || h <= 0) return FL_ERR_INVALID;
+  return run_stage(ctx, depth, (size_t)w * h * 2, dst, (size_t)w * h, (size_t)w * h, mem,
+                   [&](const uint8_t *i, uint8_t *o, uint8_t *t) {
+                     return fl_launch_quantized_normals(ctx, (const uint16_t *)i, 0, o, 0, t, 0, 1, w, h,
+                                                        distance_threshold, difference_threshold);
+                   });
+}
+
+extern "C" int fl_pyrdown_bgr(fl_context *ctx, const uint8_t *src, int w, int h, uint8_t *dst, int mem)
+{
+  if (!ctx || !src || !dst || w < 2 || h < 2) return FL_ERR_INVALID;
+  return run_stage(ctx, src, (size_t)w * h * 3, dst, (size_t)(w / 2) * (h / 2) * 3, 0, mem,
+                   [&](const uint8_t *i, uint8_t *o, uint8_t *) { return fl_launch_pyrdown_bgr(ctx, i, 0, o, 0, 1, w, h); });
+}

@@ -1,0 +1,1019 @@
+// fl_icp.hip -- gfx950 kernels for the ICP half of the FEALESS hot path.
+//
+// Replaces (reference paths): cup_d2pc::depthTo3d (ICP/depth_to_3d.cpp:99-137,190-269),
+// scale_mat_vec3f / matToVec / is_vec3f_valid (ICP/common.cpp:261-266,382-425), detection()
+// (ICP/detection.cpp:11-254), icpCloudToCloud_Ex + getMean/transformPoints/getL2distClouds/
+// PointsCorresponding (ICP/ICP.cpp:8-111,193-279,617-809) and the tail of
+// CObjRecoLmICP::Recognition (CadReco/obj_reco_lmicp.cpp:111-199).
+//
+// Execution model: ONE workgroup owns one frame's whole refinement -- crop back-projection,
+// paired-valid compaction, centroid pre-alignment, every ICP iteration and the final pose -- in
+// a single launch; a batch is a grid of such workgroups.  No host round trip and no inter-
+// workgroup synchronisation exists anywhere in the path: phases inside a frame are separated by
+// workgroup barriers only.  Parallelism comes from frames (hundreds to thousands resident in
+// 288 GB HBM), which is what lets the reference's strictly sequential float32 sums be kept:
+//   * FL_ICP_PARITY: each of the 15 centroid/covariance scalars (and the distance sum) is a
+//     float32 chain accumulated in the reference's order by its own lane; dropped pairs add an
+//     exact +0.0f so the chain is branch-free.  Bit-identical to the reference's arithmetic.
+//   * FL_ICP_FAST: fp64 per-thread partials + fixed-shape tree, rounded once to float32.
+// Nearest neighbours: the reference's FLANN kd-tree (exact 1-NN, eps 0) is replaced by a uniform
+// x/y cell grid over the static reference cloud built once per frame; a query only visits the
+// cells within sqrt(3*dist_mean) because farther neighbours are discarded anyway
+// (PointsCorresponding keeps d^2 <= 3*dist_mean, ICP.cpp:268,708).  Distances use L2_Simple's
+// float expression ((dx*dx + dy*dy) + dz*dz); ties go to the lowest index.
+// Built with -ffp-contract=off: one IEEE binary32/64 operation per operator.
+#include "fl_internal.h"
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#define ICP_MAX_THREADS 1024
+
+struct IcpWsLayout {
+  size_t ref, mod, sref, sidx, prod, dterm, cell_start, cell_cur, total;
+  int ncell_max;
+};
+static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static __host__ __device__ inline IcpWsLayout icp_layout(int n)
+{
+  IcpWsLayout L;
+  size_t o = 0, nn = (size_t)(n > 0 ? n : 1);
+  L.ncell_max = n + 4096;
+  L.ref = o; o = al256(o + 12 * nn);
+  L.mod = o; o = al256(o + 12 * nn);
+  L.sref = o; o = al256(o + 12 * nn);
+  L.sidx = o; o = al256(o + 4 * nn);
+  L.prod = o; o = al256(o + 64 * nn);
+  L.dterm = o; o = al256(o + 4 * nn);
+  L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
+  L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
+  L.total = o;
+  return L;
+}
+size_t fl_icp_ws_bytes(int n_pts_max) { return icp_layout(n_pts_max).total; }
+
+struct IcpJob {          // what one workgroup needs besides its workspace
+  int kind;              // 0: recognition (read the frame's best match), 1: detection, 2: clouds given
+  int n_ref, n_model;    // kind 2
+  int rect_model[4], rect_ref[4];      // kind 1
+  float r_match[9], t_match[3];        // kind 1
+  const uint16_t *model_depth;         // kind 1 (mm)
+  const uint16_t *scene_depth;         // kind 1 (mm)
+};
+
+struct IcpArgs {
+  uint8_t *ws;           // frame 0's ICP workspace
+  size_t ws_stride;
+  int n_max;
+  // scene
+  int w, h;
+  float fx, fy, cx, cy;  // (float)dFx ... as Mat_<float> K would hold them (common.cpp:374-379)
+  int it_thr;
+  float dmt, ddt;
+  int mode;
+  IcpJob job;            // kinds 1, 2
+  // kind 0: recognition batch
+  const uint8_t *frame_ws;   // detector frame workspaces (same stride)
+  size_t off_count, off_match;
+  const uint16_t *scene_base;   // frame i's depth = scene_base + i*scene_stride (bytes)
+  size_t scene_stride;
+  const FlPyrInfo *pyr;
+  const int *class_first;
+  const float *poses;
+  const uint16_t *const *depth_ptrs;
+  fl_recognition_result *results;
+};
+
+struct IcpShared {
+  float R[9], T[3], Ropt[9], Topt[3];
+  float dist_mean, dist_diff, px, thr;
+  int iter, n_corr, go, ok;
+  float xmin, ymin, inv_c;
+  int GX, GY;
+  float sums[16];
+  double dsum[16][16];   // [wave][scalar]
+  int iscan[ICP_MAX_THREADS / 64 + 1];
+  int ibase;
+  int ired[4][16];
+  float fred[4][16];
+  float t_init[3];
+  int n, rect_m[4], rect_r[4], status, g;
+};
+
+__device__ __forceinline__ bool vvalid(float z) { return z <= 900.0f; }      // common.cpp:261-266
+
+// ---- block-level helpers (every thread of the workgroup must call) ---------------------------
+__device__ int block_excl_scan(IcpShared &S, int v, int *total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) S.iscan[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < nw; ++i) { int t = S.iscan[i]; S.iscan[i] = run; run += t; }
+    S.iscan[nw] = run;
+  }
+  __syncthreads();
+  *total = S.iscan[nw];
+  return S.iscan[wave] + inc - v;
+}
+
+__device__ int block_sum_int(IcpShared &S, int v)
+{
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) S.iscan[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int t = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += S.iscan[i];
+  return t;
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int s)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, s, 64);
+  hi = __shfl_xor(hi, s, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// fixed-shape fp64 reduction of NS scalars per thread -> S.sums[k] as float is NOT done here: the
+// caller rounds.  Result (double) valid in thread 0..NS-1's return slot via S.dsum[0][k].
+template <int NS>
+__device__ void block_sum_double(IcpShared &S, double *v)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) x += shfl_xor_d(x, s);
+    v[k] = x;
+  }
+  __syncthreads();
+  if (lane == 0)
+    for (int k = 0; k < NS; ++k) S.dsum[wave][k] = v[k];
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double t = 0;
+    for (int i = 0; i < nw; ++i) t += S.dsum[i][threadIdx.x];
+    S.dsum[0][threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// ---- 3x3 helpers with cv::Matx float semantics (s = 0; s += a*b ...) --------------------------
+__device__ __forceinline__ void mat_vec(const float *R, const float *v, float *o)
+{
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float s = 0;
+    s += R[i * 3 + 0] * v[0];
+    s += R[i * 3 + 1] * v[1];
+    s += R[i * 3 + 2] * v[2];
+    o[i] = s;
+  }
+}
+__device__ __forceinline__ void mat_mat(const float *A, const float *B, float *O)
+{
+  float t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float s = 0;
+      for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j];
+      t[i * 3 + j] = s;
+    }
+  for (int i = 0; i < 9; ++i) O[i] = t[i];
+}
+
+// cv::SVD::compute on 3x3 CV_32F: OpenCV JacobiSVDImpl_<float> restated (same text as
+// oracle/icp_oracle.c orc_svd3, which documents the one deviation: hypot -> sqrt(p*p+b*b)).
+__device__ void svd3(const float *A, float *U, float *Vt)
+{
+  float At[9];
+  double W[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) At[i * 3 + j] = A[j * 3 + i];
+  const float eps = FLT_EPSILON * 2;
+  const double minval = FLT_MIN;
+  for (int i = 0; i < 3; ++i) {
+    double sd = 0;
+    for (int k = 0; k < 3; ++k) { float t = At[i * 3 + k]; sd += (double)t * t; }
+    W[i] = sd;
+    for (int k = 0; k < 3; ++k) Vt[i * 3 + k] = 0;
+    Vt[i * 3 + i] = 1;
+  }
+  for (int iter = 0; iter < 30; ++iter) {
+    bool changed = false;
+    for (int i = 0; i < 2; ++i)
+      for (int j = i + 1; j < 3; ++j) {
+        float *Ai = At + i * 3, *Aj = At + j * 3;
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < 3; ++k) p += (double)Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt((double)a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = sqrt(p * p + beta * beta);
+        float c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = (float)sqrt(delta / gamma);
+          c = (float)(p / (gamma * s * 2));
+        } else {
+          c = (float)sqrt((gamma + beta) / (gamma * 2));
+          s = (float)(p / (gamma * c * 2));
+        }
+        a = b = 0;
+        for (int k = 0; k < 3; ++k) {
+          float t0 = c * Ai[k] + s * Aj[k];
+          float t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          a += (double)t0 * t0;
+          b += (double)t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+        float *Vi = Vt + i * 3, *Vj = Vt + j * 3;
+        for (int k = 0; k < 3; ++k) {
+          float t0 = c * Vi[k] + s * Vj[k];
+          float t1 = -s * Vi[k] + c * Vj[k];
+          Vi[k] = t0;
+          Vj[k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < 3; ++i) {
+    double sd = 0;
+    for (int k = 0; k < 3; ++k) { float t = At[i * 3 + k]; sd += (double)t * t; }
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < 2; ++i) {
+    int j = i;
+    for (int k = i + 1; k < 3; ++k)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double t = W[i]; W[i] = W[j]; W[j] = t;
+      for (int k = 0; k < 3; ++k) { float f = At[i * 3 + k]; At[i * 3 + k] = At[j * 3 + k]; At[j * 3 + k] = f; }
+      for (int k = 0; k < 3; ++k) { float f = Vt[i * 3 + k]; Vt[i * 3 + k] = Vt[j * 3 + k]; Vt[j * 3 + k] = f; }
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    double sd = W[i];
+    float s = (float)(sd > minval ? 1 / sd : 0.);
+    for (int k = 0; k < 3; ++k) At[i * 3 + k] *= s;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) U[i * 3 + j] = At[j * 3 + i];
+}
+
+__device__ __forceinline__ bool finite_all(const float *v, int n)
+{
+  for (int i = 0; i < n; ++i)
+    if (!isfinite(v[i])) return false;
+  return true;
+}
+
+// ---- sequential float32 chains (FL_ICP_PARITY) ------------------------------------------------
+// lane k < width accumulates column k of a row-major [n][stride] float table, in row order.
+__device__ __forceinline__ float chain_sum(const float *tab, int n, int stride, int k, bool active)
+{
+  float acc = 0.0f;
+  if (active) {
+    const float *p = tab + k;
+    int i = 0;
+    for (; i + 16 <= n; i += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(i + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; i < n; ++i) acc += p[(size_t)i * stride];
+  }
+  return acc;
+}
+
+// ---- uniform x/y grid over the reference cloud --------------------------------------------------
+__device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
+{
+  float t = floorf((v - vmin) * inv_c);
+  int c = t < 0.f ? 0 : (t > (float)(G - 1) ? G - 1 : (int)t);
+  return c;
+}
+
+__device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float *sref, int *sidx, int *cell_start,
+                           int *cell_cur, int ncell_max)
+{
+  // bounding box of the finite points
+  float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+  for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
+    const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      xmin = fminf(xmin, x);
+      xmax = fmaxf(xmax, x);
+      ymin = fminf(ymin, y);
+      ymax = fmaxf(ymax, y);
+    }
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    xmin = fminf(xmin, __shfl_xor(xmin, s, 64));
+    xmax = fmaxf(xmax, __shfl_xor(xmax, s, 64));
+    ymin = fminf(ymin, __shfl_xor(ymin, s, 64));
+    ymax = fmaxf(ymax, __shfl_xor(ymax, s, 64));
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    const int wv = threadIdx.x >> 6;
+    S.fred[0][wv] = xmin;
+    S.fred[1][wv] = xmax;
+    S.fred[2][wv] = ymin;
+    S.fred[3][wv] = ymax;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+      xmin = fminf(xmin, S.fred[0][i]);
+      xmax = fmaxf(xmax, S.fred[1][i]);
+      ymin = fminf(ymin, S.fred[2][i]);
+      ymax = fmaxf(ymax, S.fred[3][i]);
+    }
+    if (!(xmax >= xmin)) { xmin = xmax = 0.f; ymin = ymax = 0.f; }
+    const float dx = xmax - xmin, dy = ymax - ymin;
+    float c = sqrtf((dx * dy) / (float)(n_ref > 0 ? n_ref : 1) * 2.0f);
+    if (!(c > 0.25f)) c = 0.25f;
+    int GX, GY;
+    for (;;) {
+      GX = (int)(dx / c) + 1;
+      GY = (int)(dy / c) + 1;
+      if ((long long)GX * GY <= ncell_max) break;
+      c *= 1.5f;
+    }
+    S.xmin = xmin;
+    S.ymin = ymin;
+    S.inv_c = 1.0f / c;
+    S.GX = GX;
+    S.GY = GY;
+  }
+  __syncthreads();
+  const int ncell = S.GX * S.GY;
+  for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
+    const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z))
+      atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the counts -> cell_start
+  if (threadIdx.x == 0) S.ibase = 0;
+  __syncthreads();
+  for (int base = 0; base < ncell; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    const int v = i < ncell ? cell_cur[i] : 0;
+    int total;
+    const int ex = block_excl_scan(S, v, &total);
+    if (i < ncell) cell_start[i] = S.ibase + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) S.ibase += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cell_start[ncell] = S.ibase;
+  for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = cell_start[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
+    const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
+    if (isfinite(x) && isfinite(y) && isfinite(z)) {
+      const int slot = atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
+      sref[3 * slot] = x;
+      sref[3 * slot + 1] = y;
+      sref[3 * slot + 2] = z;
+      sidx[slot] = i;
+    }
+  }
+  __syncthreads();
+}
+
+// exact 1-NN within squared distance thr (float compare as the reference's `dists <= dist_thr`)
+__device__ __forceinline__ void nn_query(const IcpShared &S, const float *sref, const int *sidx, const int *cell_start,
+                                         float qx, float qy, float qz, float thr, int *bi, float *bd)
+{
+  int best_i = -1;
+  float best_d = INFINITY;
+  if (thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+    // conservative search radius: float rounding of d2 and of the differences is far below the margin
+    float r = isfinite(thr) ? sqrtf(thr) * 1.0001f + 1e-3f : INFINITY;
+    int cx0 = 0, cx1 = S.GX - 1, cy0 = 0, cy1 = S.GY - 1;
+    if (isfinite(r)) {
+      cx0 = cell_of(qx - r, S.xmin, S.inv_c, S.GX);
+      cx1 = cell_of(qx + r, S.xmin, S.inv_c, S.GX);
+      cy0 = cell_of(qy - r, S.ymin, S.inv_c, S.GY);
+      cy1 = cell_of(qy + r, S.ymin, S.inv_c, S.GY);
+    }
+    for (int cy = cy0; cy <= cy1; ++cy) {
+      const int b = cell_start[cy * S.GX + cx0], e = cell_start[cy * S.GX + cx1 + 1];   // cells of a row are contiguous
+      for (int s = b; s < e; ++s) {
+        const float dx = qx - sref[3 * s], dy = qy - sref[3 * s + 1], dz = qz - sref[3 * s + 2];
+        float d = dx * dx;                              // cvflann::L2_Simple<float>
+        d += dy * dy;
+        d += dz * dz;
+        const int j = sidx[s];
+        if (d < best_d || (d == best_d && j < best_i)) { best_d = d; best_i = j; }
+      }
+    }
+  }
+  *bi = best_i;
+  *bd = best_i >= 0 ? best_d : NAN;
+}
+
+// ---- getL2distClouds (ICP.cpp:68-111) over the index-paired clouds ------------------------------
+__device__ void l2dist_phase(IcpShared &S, const float *mod, const float *ref, float *dterm, int n, float thr, int mode,
+                             const float *Ropt, const float *Topt, float *mod_w)
+{
+  int counter = 0, inl = 0;
+  double dsum[1] = {0.0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float a[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]};
+    if (Ropt && vvalid(a[2])) {                           // transformPoints in place (:28-45, :756)
+      float o[3];
+      mat_vec(Ropt, a, o);
+      a[0] = o[0] + Topt[0];
+      a[1] = o[1] + Topt[1];
+      a[2] = o[2] + Topt[2];
+      mod_w[3 * i] = a[0];
+      mod_w[3 * i + 1] = a[1];
+      mod_w[3 * i + 2] = a[2];
+    }
+    const float b0 = ref[3 * i], b1 = ref[3 * i + 1], b2 = ref[3 * i + 2];
+    float term = 0.0f;
+    if (vvalid(b2) && vvalid(a[2])) {
+      const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
+      // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
+      const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+      if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
+      ++counter;
+    }
+    dterm[i] = term;
+  }
+  counter = block_sum_int(S, counter);
+  inl = block_sum_int(S, inl);
+  float dm;
+  if (mode == FL_ICP_PARITY) {
+    __syncthreads();                                     // dterm visible to wave 0
+    float acc = 0.f;
+    if (threadIdx.x < 64) acc = chain_sum(dterm, n, 1, 0, threadIdx.x == 0);
+    if (threadIdx.x == 0) S.sums[0] = acc;
+    __syncthreads();
+    dm = S.sums[0];
+    if (counter > 0) dm /= (float)inl;                   // 0/0 -> NaN ends the loop (Q9)
+  } else {
+    block_sum_double<1>(S, dsum);
+    dm = counter > 0 ? (float)(S.dsum[0][0] / (double)inl) : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    if (counter > 0) {
+      S.dist_mean = dm;
+      S.px = (float)inl / (float)counter;
+    } else {
+      S.dist_mean = FLT_MAX;
+      S.px = 0.0f;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- icpCloudToCloud_Ex (ICP.cpp:617-809) --------------------------------------------------------
+__device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model, int it_thr, float dmt,
+                        float ddt, int mode, fl_icp_result *res)
+{
+  float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod), *sref = (float *)(wsb + L.sref);
+  int *sidx = (int *)(wsb + L.sidx), *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
+  float *prod = (float *)(wsb + L.prod), *dterm = (float *)(wsb + L.dterm);
+
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) S.R[i] = 0.f;           // cv::Matx33f R; cv::Vec3f T; zero-initialised
+    for (int i = 0; i < 3; ++i) S.T[i] = 0.f;
+    S.iter = 0;
+    S.n_corr = 0;
+    S.px = 0.f;
+  }
+  __syncthreads();
+  if (n_model < 3 || n_ref < 3 || n_ref < n_model) {    // :633-638 (n_ref < n_model: reference reads OOB)
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 9; ++i) res->R[i] = 0.f;
+      for (int i = 0; i < 3; ++i) res->T[i] = 0.f;
+      res->dist_mean = -1.0f;
+      res->px_ratio = 0.f;
+      res->iters = 0;
+      res->n_corr_last = 0;
+    }
+    __syncthreads();
+    return;
+  }
+  build_grid(S, ref, n_ref, sref, sidx, cell_start, cell_cur, L.ncell_max);
+  // copyPoints(pts_model, pts_model_tmp) (:666-667): invalid points become Vec3f() = 0
+  for (int i = threadIdx.x; i < n_model; i += blockDim.x)
+    if (!vvalid(mod[3 * i + 2])) { mod[3 * i] = 0.f; mod[3 * i + 1] = 0.f; mod[3 * i + 2] = 0.f; }
+  if (threadIdx.x == 0) {
+    S.R[0] = S.R[4] = S.R[8] = 1.f;                      // R = eye, T = 0 (:644-645)
+    S.dist_diff = FLT_MAX;
+  }
+  __syncthreads();
+  l2dist_phase(S, mod, ref, dterm, n_model, FLT_MAX, mode, nullptr, nullptr, nullptr);   // :670
+
+  for (;;) {
+    if (threadIdx.x == 0) S.go = (S.dist_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);   // :684
+    __syncthreads();
+    if (!S.go) break;
+    if (threadIdx.x == 0) { ++S.iter; S.thr = 3 * S.dist_mean; }
+    __syncthreads();
+    const int iter = S.iter;
+    const float thr = S.thr;
+    const int rows = iter == 1 ? n_ref : n_model;
+    int kept = 0;
+    double ds[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) ds[k] = 0.0;
+    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+      float m[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+      bool have_m = false, have_pair = false;
+      if (iter == 1) {                                   // :700-704: index pairs, invalid -> 0
+        if (i < n_model) {
+          have_m = true;
+          have_pair = true;
+          if (vvalid(mod[3 * i + 2])) { m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2]; }
+        }
+        if (vvalid(ref[3 * i + 2])) { r[0] = ref[3 * i]; r[1] = ref[3 * i + 1]; r[2] = ref[3 * i + 2]; }
+      } else {                                           // PointsCorresponding :193-279
+        int j;
+        float d;
+        const float qx = mod[3 * i], qy = mod[3 * i + 1], qz = mod[3 * i + 2];
+        nn_query(S, sref, sidx, cell_start, qx, qy, qz, thr, &j, &d);
+        if (d <= thr) {
+          have_m = have_pair = true;
+          m[0] = qx; m[1] = qy; m[2] = qz;
+          r[0] = ref[3 * j]; r[1] = ref[3 * j + 1]; r[2] = ref[3 * j + 2];
+          ++kept;
+        }
+      }
+      float row[16];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) row[a * 3 + b] = have_pair ? m[a] * r[b] : 0.0f;   // (*it_s) * (*it_ref).t()
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { row[9 + k] = have_m ? m[k] : 0.0f; row[12 + k] = r[k]; }
+      row[15] = 0.0f;
+      if (mode == FL_ICP_PARITY) {
+        float4 *dst = (float4 *)(prod + (size_t)i * 16);
+        dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+        dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+        dst[2] = make_float4(row[8], row[9], row[10], row[11]);
+        dst[3] = make_float4(row[12], row[13], row[14], row[15]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) ds[a * 3 + b] += (double)m[a] * (double)r[b] * (have_pair ? 1.0 : 0.0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ds[9 + k] += have_m ? (double)m[k] : 0.0; ds[12 + k] += (double)r[k]; }
+      }
+    }
+    kept = block_sum_int(S, kept);
+    const int ncm = iter == 1 ? n_model : kept, ncr = iter == 1 ? n_ref : kept;
+    if (threadIdx.x == 0) S.n_corr = ncm;
+    if (ncr < 3 || ncm < 3) {                            // :711-715
+      __syncthreads();
+      if (threadIdx.x == 0) S.iter = it_thr;
+      __syncthreads();
+      continue;
+    }
+    if (mode == FL_ICP_PARITY) {
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const float acc = chain_sum(prod, rows, 16, threadIdx.x & 15, threadIdx.x < 15);
+        if (threadIdx.x < 15) S.sums[threadIdx.x] = acc;
+      }
+      __syncthreads();
+    } else {
+      block_sum_double<15>(S, ds);
+    }
+    if (threadIdx.x == 0) {
+      float C[9], mc[3], rc[3];
+      if (mode == FL_ICP_PARITY) {
+        for (int k = 0; k < 9; ++k) C[k] = S.sums[k];
+        for (int k = 0; k < 3; ++k) { mc[k] = S.sums[9 + k] / (float)ncm; rc[k] = S.sums[12 + k] / (float)ncr; }   // getMean :19-24
+      } else {
+        for (int k = 0; k < 9; ++k) C[k] = (float)S.dsum[0][k];
+        for (int k = 0; k < 3; ++k) { mc[k] = (float)(S.dsum[0][9 + k] / ncm); rc[k] = (float)(S.dsum[0][12 + k] / ncr); }
+      }
+      float u[9], vt[9];
+      svd3(C, u, vt);                                    // :742
+      for (int i = 0; i < 3; ++i)                        // R_optimal = Mat(vt.t() * u.t()) :744 (gemm: double acc)
+        for (int j = 0; j < 3; ++j) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += (double)vt[k * 3 + i] * (double)u[j * 3 + k];
+          S.Ropt[i * 3 + j] = (float)s;
+        }
+      float Rm[3];
+      mat_vec(S.Ropt, mc, Rm);
+      for (int k = 0; k < 3; ++k) S.Topt[k] = rc[k] - Rm[k];                      // :747
+      S.ok = finite_all(S.Ropt, 9) && finite_all(S.Topt, 3);                      // checkRange :748
+    }
+    __syncthreads();
+    if (!S.ok) continue;                                 // :749
+    float Ro[9], To[3];
+    for (int k = 0; k < 9; ++k) Ro[k] = S.Ropt[k];
+    for (int k = 0; k < 3; ++k) To[k] = S.Topt[k];
+    const float old_mean = S.dist_mean;
+    __syncthreads();
+    l2dist_phase(S, mod, ref, dterm, n_model, 3 * old_mean, mode, Ro, To, mod);   // :756, :778-780
+    if (threadIdx.x == 0) {
+      S.dist_diff = old_mean - S.dist_mean;
+      float RT[3];                                       // :793-797
+      mat_vec(S.Ropt, S.T, RT);
+      for (int k = 0; k < 3; ++k) S.T[k] = RT[k] + S.Topt[k];
+      mat_mat(S.Ropt, S.R, S.R);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) res->R[i] = S.R[i];
+    for (int i = 0; i < 3; ++i) res->T[i] = S.T[i];
+    res->dist_mean = S.dist_mean;
+    res->px_ratio = S.px;
+    res->iters = S.iter;
+    res->n_corr_last = S.n_corr;
+  }
+  __syncthreads();
+}
+
+// ---- detection() front half: crop back-projection + paired-valid compaction ----------------------
+__device__ int crop_clouds(IcpShared &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
+                           const int *rm, const int *rr, float *ref, float *mod)
+{
+  const int cw = rm[2], ch = rm[3], np = cw * ch;
+  const float inv_fx = 1.0f / a.fx, inv_fy = 1.0f / a.fy;                        // depth_to_3d.cpp:103-104
+  const float minv_fx = 1.0f / 608.f, minv_fy = 1.0f / 608.f;                   // initInternalMat common.cpp:358
+  const float zs = (float)(1 / 1000.0);
+  if (threadIdx.x == 0) S.ibase = 0;
+  __syncthreads();
+  for (int base = 0; base < np; base += blockDim.x) {
+    const int p = base + threadIdx.x;
+    float A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
+    int keep = 0;
+    if (p < np) {
+      const int y = p / cw, x = p - y * cw;
+      const int sx = rr[0] + x, sy = rr[1] + y, mx = rm[0] + x, my = rm[1] + y;
+      const unsigned ds = scene[(size_t)sy * a.w + sx];
+      unsigned dm = model[(size_t)my * a.w + mx];
+      if (model_01mm) {                                  // convertTo(CV_16UC1, 0.1) obj_reco_lmicp.cpp:188
+        int v = __float2int_rn((float)dm * 0.1f);
+        dm = (unsigned)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+      }
+      const float zsf = ds == 0 ? NAN : (float)ds * zs;                           // rescaleDepth :257-259
+      const float zmf = dm == 0 ? NAN : (float)dm * zs;
+      A[0] = ((((float)sx - a.cx) * inv_fx) * zsf) * 1000;                        // :119,:132; scale_mat_vec3f
+      A[1] = ((((float)sy - a.cy) * inv_fy) * zsf) * 1000;
+      A[2] = zsf * 1000;
+      B[0] = ((((float)mx - 320.f) * minv_fx) * zmf) * 1000;
+      B[1] = ((((float)my - 240.f) * minv_fy) * zmf) * 1000;
+      B[2] = zmf * 1000;
+      keep = vvalid(A[2]) && vvalid(B[2]);                                        // matToVec common.cpp:382-405
+    }
+    int total;
+    const int ex = block_excl_scan(S, keep, &total);
+    if (keep) {
+      const int k = S.ibase + ex;
+      ref[3 * k] = A[0]; ref[3 * k + 1] = A[1]; ref[3 * k + 2] = A[2];
+      mod[3 * k] = B[0]; mod[3 * k + 1] = B[1]; mod[3 * k + 2] = B[2];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) S.ibase += total;
+    __syncthreads();
+  }
+  return S.ibase;
+}
+
+__global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_pipeline(IcpArgs a)
+{
+  __shared__ IcpShared S;
+  const int frame = blockIdx.x;
+  const IcpWsLayout L = icp_layout(a.n_max);
+  uint8_t *wsb = a.ws + (size_t)frame * a.ws_stride;
+  float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
+
+  if (a.job.kind == 2) {                                 // clouds already staged by the host
+    icp_run(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, a.mode, &a.results[frame].det.icp);
+    return;
+  }
+
+  fl_recognition_result *res = &a.results[frame];
+  const uint16_t *scene, *model;
+  float r_match[9], t_match[3];
+  bool model_01mm;
+  if (a.job.kind == 1) {
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < 4; ++k) { S.rect_m[k] = a.job.rect_model[k]; S.rect_r[k] = a.job.rect_ref[k]; }
+      S.status = FL_OK;
+      res->status = FL_OK;
+      res->found = 1;
+    }
+    scene = a.job.scene_depth;
+    model = a.job.model_depth;
+    for (int k = 0; k < 9; ++k) r_match[k] = a.job.r_match[k];
+    for (int k = 0; k < 3; ++k) t_match[k] = a.job.t_match[k];
+    model_01mm = false;
+    __syncthreads();
+  } else {
+    // CObjRecoLmICP::Recognition after Detector::match (obj_reco_lmicp.cpp:106-152)
+    const uint8_t *fws = a.frame_ws + (size_t)frame * a.ws_stride;
+    const int *counters = (const int *)(fws + a.off_count);
+    const fl_match *matches = (const fl_match *)(fws + a.off_match);
+    if (threadIdx.x == 0) {
+      S.status = FL_OK;
+      S.g = -1;
+      res->n_matches = counters[1];
+      res->found = 0;
+      res->status = FL_OK;
+      if (counters[2]) S.status = res->status = FL_ERR_OVERFLOW;
+      else if (counters[1] > 0) {
+        const fl_match best = matches[0];                // matches[0] :111
+        res->best = best;
+        const int g = a.class_first[best.class_idx] + best.template_id;
+        const FlPyrInfo pi = a.pyr[g];
+        S.g = g;
+        S.rect_m[0] = pi.off_x0; S.rect_m[1] = pi.off_y0; S.rect_m[2] = pi.width0; S.rect_m[3] = pi.height0;   // :129
+        S.rect_r[0] = best.x; S.rect_r[1] = best.y; S.rect_r[2] = pi.width0; S.rect_r[3] = pi.height0;         // :130-132
+        if (!a.depth_ptrs[g]) S.status = res->status = FL_ERR_STATE;      // no depth/<id>.png uploaded
+      }
+    }
+    __syncthreads();
+    if (S.g < 0 || S.status != FL_OK) return;            // vtResult stays empty (:106-109)
+    const int g = S.g;
+    scene = (const uint16_t *)((const uint8_t *)a.scene_base + (size_t)frame * a.scene_stride);
+    model = a.depth_ptrs[g];
+    const float *p = a.poses + 13 * (size_t)g;           // :141-152
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) r_match[i * 3 + j] = p[i * 4 + j];
+      t_match[i] = p[i * 4 + 3];
+    }
+    model_01mm = true;
+  }
+  // Q10: a rect leaving the image is a cv::Mat ROI assertion in the reference (detection.cpp:43-44)
+  {
+    const int *rm = S.rect_m, *rr = S.rect_r;
+    const bool bad = rm[0] < 0 || rm[1] < 0 || rm[2] < 0 || rm[3] < 0 || rm[0] + rm[2] > a.w || rm[1] + rm[3] > a.h ||
+                     rr[0] < 0 || rr[1] < 0 || rr[2] < 0 || rr[3] < 0 || rr[0] + rr[2] > a.w || rr[1] + rr[3] > a.h ||
+                     rm[2] != rr[2] || rm[3] != rr[3] || (long long)rm[2] * rm[3] > a.n_max;
+    if (bad) {
+      if (threadIdx.x == 0) { res->status = FL_ERR_ASSERT; res->det.status = FL_ERR_ASSERT; res->found = 0; }
+      return;
+    }
+  }
+  const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod);
+  // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
+  float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
+  if (a.mode == FL_ICP_PARITY) {
+    if (threadIdx.x < 64) {
+      const int k = threadIdx.x;
+      const float acc = chain_sum(k < 3 ? mod : ref, np, 3, k < 3 ? k : k - 3, k < 6);
+      if (k < 6) S.sums[k] = acc;
+    }
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) { mc[k] = S.sums[k]; rc[k] = S.sums[3 + k]; }
+    if (np > 0)
+      for (int k = 0; k < 3; ++k) { mc[k] /= (float)np; rc[k] /= (float)np; }
+  } else {
+    double ds[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+      for (int k = 0; k < 3; ++k) { ds[k] += mod[3 * i + k]; ds[3 + k] += ref[3 * i + k]; }
+    block_sum_double<6>(S, ds);
+    if (np > 0)
+      for (int k = 0; k < 3; ++k) { mc[k] = (float)(S.dsum[0][k] / np); rc[k] = (float)(S.dsum[0][3 + k] / np); }
+  }
+  float t_tmp[3], t_init[3];
+  for (int k = 0; k < 3; ++k) { t_tmp[k] = rc[k] - mc[k]; t_init[k] = t_tmp[k] + t_match[k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < np; i += blockDim.x) {   // transformPoints(pts_mod, I, t_match_tmp) :206
+    if (!vvalid(mod[3 * i + 2])) continue;
+    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    float v[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]}, o[3];
+    mat_vec(I, v, o);
+    mod[3 * i] = o[0] + t_tmp[0];
+    mod[3 * i + 1] = o[1] + t_tmp[1];
+    mod[3 * i + 2] = o[2] + t_tmp[2];
+  }
+  __syncthreads();
+  icp_run(S, wsb, L, np, np, a.it_thr, a.dmt, a.ddt, a.mode, &res->det.icp);      // :228
+  if (threadIdx.x == 0) {
+    const fl_icp_result &ic = res->det.icp;
+    float Rt[3];
+    mat_vec(ic.R, t_init, Rt);                           // T_final = R*t_init + T, R_final = R*r_match :232-234
+    for (int k = 0; k < 3; ++k) res->det.T_final[k] = Rt[k] + ic.T[k];
+    mat_mat(ic.R, r_match, res->det.R_final);
+    res->det.n_points = np;
+    res->det.status = FL_OK;
+    for (int i = 0; i < 3; ++i) {                        // Convert() obj_reco_lmicp.cpp:20-30
+      for (int j = 0; j < 3; ++j) res->pose[i * 4 + j] = res->det.R_final[i * 3 + j];
+      res->pose[i * 4 + 3] = res->det.T_final[i];
+    }
+    res->pose[12] = res->pose[13] = res->pose[14] = 0.f;
+    res->pose[15] = 1.f;
+    res->found = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// cup_d2pc::depthTo3d full frame (the stage entry point; the pipeline only back-projects crops)
+__global__ __launch_bounds__(256) void k_depth_to_3d(const uint16_t *__restrict__ depth, int w, int h, float fx, float fy,
+                                                     float cx, float cy, float *__restrict__ out)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float inv_fx = 1.0f / fx, inv_fy = 1.0f / fy;
+  const unsigned d = depth[(size_t)y * w + x];
+  const float z = d == 0 ? NAN : (float)d * (float)(1 / 1000.0);
+  float *p = out + ((size_t)y * w + x) * 3;
+  p[0] = (((float)x - cx) * inv_fx) * z;
+  p[1] = (((float)y - cy) * inv_fy) * z;
+  p[2] = z;
+}
+
+extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int h, double fx, double fy, double cx,
+                              double cy, float *out, int mem)
+{
+  if (!ctx || !depth || !out || w <= 0 || h <= 0) return FL_ERR_INVALID;
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nin = (size_t)w * h * 2, nout = (size_t)w * h * 12;
+  const uint16_t *din = depth;
+  float *dout = out;
+  if (mem == FL_MEM_HOST) {
+    void *s = nullptr;
+    int rc = fl_scratch(ctx, fl_align(nin, 256) + nout, &s);
+    if (rc) return rc;
+    FL_HIP(ctx, hipMemcpyAsync(s, depth, nin, hipMemcpyHostToDevice, ctx->stream));
+    din = (const uint16_t *)s;
+    dout = (float *)((uint8_t *)s + fl_align(nin, 256));
+  }
+  dim3 grid((w + 63) / 64, (h + 3) / 4);
+  hipLaunchKernelGGL(k_depth_to_3d, grid, dim3(256), 0, ctx->stream, din, w, h, (float)fx, (float)fy, (float)cx, (float)cy,
+                     dout);
+  FL_HIP(ctx, hipGetLastError());
+  if (mem == FL_MEM_HOST) {
+    FL_HIP(ctx, hipMemcpyAsync(out, dout, nout, hipMemcpyDeviceToHost, ctx->stream));
+    FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return FL_OK;
+}
+
+static int icp_threads(int n_frames) { return n_frames >= 192 ? 256 : (n_frames >= 48 ? 512 : 1024); }
+
+extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model, int icp_it_thr,
+                      float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem, fl_icp_result *res)
+{
+  if (!ctx || !res || n_ref < 0 || n_model < 0 || (n_ref && !ref) || (n_model && !model)) return FL_ERR_INVALID;
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const int n_max = n_ref > n_model ? n_ref : n_model;
+  const IcpWsLayout L = icp_layout(n_max);
+  void *s = nullptr;
+  int rc = fl_scratch(ctx, L.total + 4096, &s);
+  if (rc) return rc;
+  uint8_t *wsb = (uint8_t *)s;
+  fl_recognition_result *dres = (fl_recognition_result *)(wsb + L.total);
+  const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (n_ref) FL_HIP(ctx, hipMemcpyAsync(wsb + L.ref, ref, 12 * (size_t)n_ref, kind, ctx->stream));
+  if (n_model) FL_HIP(ctx, hipMemcpyAsync(wsb + L.mod, model, 12 * (size_t)n_model, kind, ctx->stream));
+  IcpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ws = wsb;
+  a.ws_stride = 0;
+  a.n_max = n_max;
+  a.it_thr = icp_it_thr;
+  a.dmt = dist_mean_thr;
+  a.ddt = dist_diff_thr;
+  a.mode = icp_mode;
+  a.job.kind = 2;
+  a.job.n_ref = n_ref;
+  a.job.n_model = n_model;
+  a.results = dres;
+  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(1024), 0, ctx->stream, a);
+  FL_HIP(ctx, hipGetLastError());
+  fl_recognition_result *h = nullptr;
+  rc = fl_pinned(ctx, sizeof(*h), (void **)&h);
+  if (rc) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(h, dres, sizeof(*h), hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *res = h->det.icp;
+  return FL_OK;
+}
+
+extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const uint16_t *scene_depth, int w, int h,
+                            const fl_intrinsics *K, const int rect_model[4], const int rect_ref[4], int icp_it_thr,
+                            float dist_mean_thr, float dist_diff_thr, const float r_match[9], const float t_match[3],
+                            int icp_mode, int mem, fl_detection_result *res)
+{
+  if (!ctx || !model_depth || !scene_depth || !K || !rect_model || !rect_ref || !r_match || !t_match || !res || w <= 0 ||
+      h <= 0)
+    return FL_ERR_INVALID;
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  long long area = (long long)rect_model[2] * rect_model[3];
+  if (area < 0 || area > (long long)w * h) area = 0;     // the kernel reports FL_ERR_ASSERT for bad rects
+  const int n_max = (int)(area > 0 ? area : 1);
+  const IcpWsLayout L = icp_layout(n_max);
+  const size_t img = fl_align((size_t)w * h * 2, 256);
+  void *s = nullptr;
+  int rc = fl_scratch(ctx, L.total + 4096 + 2 * img, &s);
+  if (rc) return rc;
+  uint8_t *wsb = (uint8_t *)s;
+  fl_recognition_result *dres = (fl_recognition_result *)(wsb + L.total);
+  const uint16_t *dm = model_depth, *dsn = scene_depth;
+  if (mem == FL_MEM_HOST) {
+    uint8_t *b = wsb + L.total + 4096;
+    FL_HIP(ctx, hipMemcpyAsync(b, model_depth, (size_t)w * h * 2, hipMemcpyHostToDevice, ctx->stream));
+    FL_HIP(ctx, hipMemcpyAsync(b + img, scene_depth, (size_t)w * h * 2, hipMemcpyHostToDevice, ctx->stream));
+    dm = (const uint16_t *)b;
+    dsn = (const uint16_t *)(b + img);
+  }
+  FL_HIP(ctx, hipMemsetAsync(dres, 0, sizeof(*dres), ctx->stream));
+  IcpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ws = wsb;
+  a.n_max = n_max;
+  a.w = w;
+  a.h = h;
+  a.fx = (float)K->fx;
+  a.fy = (float)K->fy;
+  a.cx = (float)K->cx;
+  a.cy = (float)K->cy;
+  a.it_thr = icp_it_thr;
+  a.dmt = dist_mean_thr;
+  a.ddt = dist_diff_thr;
+  a.mode = icp_mode;
+  a.job.kind = 1;
+  for (int k = 0; k < 4; ++k) { a.job.rect_model[k] = rect_model[k]; a.job.rect_ref[k] = rect_ref[k]; }
+  for (int k = 0; k < 9; ++k) a.job.r_match[k] = r_match[k];
+  for (int k = 0; k < 3; ++k) a.job.t_match[k] = t_match[k];
+  a.job.model_depth = dm;
+  a.job.scene_depth = dsn;
+  a.results = dres;
+  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(1024), 0, ctx->stream, a);
+  FL_HIP(ctx, hipGetLastError());
+  fl_recognition_result *hres = nullptr;
+  rc = fl_pinned(ctx, sizeof(*hres), (void **)&hres);
+  if (rc) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(hres, dres, sizeof(*hres), hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *res = hres->det;
+  if (hres->status == FL_ERR_ASSERT) {
+    res->status = FL_ERR_ASSERT;
+    return fl_set_error(ctx, FL_ERR_ASSERT, "crop rectangle leaves the image (cv::Mat ROI assert, detection.cpp:43-44)");
+  }
+  return FL_OK;
+}
+
+// batch: one workgroup per frame of the detector workspace
+int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *p,
+                              const uint16_t *depth, size_t depth_stride)
+{
+  fl_context *ctx = det->ctx;
+  IcpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ws = det->d_ws + det->off_icp;
+  a.ws_stride = det->ws_stride;
+  a.n_max = det->n_pts_max;
+  a.w = det->w0;
+  a.h = det->h0;
+  a.fx = (float)K->fx;
+  a.fy = (float)K->fy;
+  a.cx = (float)K->cx;
+  a.cy = (float)K->cy;
+  a.it_thr = p->icp_it_thr;
+  a.dmt = p->dist_mean_thr;
+  a.ddt = p->dist_diff_thr;
+  a.mode = p->icp_mode;
+  a.job.kind = 0;
+  a.frame_ws = det->d_ws;
+  a.scene_base = depth;
+  a.scene_stride = depth_stride;
+  a.off_count = det->off_count;
+  a.off_match = det->off_match;
+  a.pyr = det->d_pyr;
+  a.class_first = det->d_class_first;
+  a.poses = det->d_poses;
+  a.depth_ptrs = det->d_depth_ptrs;
+  a.results = det->d_results;
+  hipLaunchKernelGGL(k_icp_pipeline, dim3(n_frames), dim3(icp_threads(n_frames)), 0, ctx->stream, a);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}

@@ -1,0 +1,154 @@
+// fl_internal.h -- shared host-side state of libfealess_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/fealess_hip.h"
+
+#define FL_WAVE 64
+
+struct fl_context {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  char err[512] = {0};
+  // scratch for the single-shot stage entry points (grown on demand)
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void *pinned = nullptr;       // small pinned host buffer for result read-back
+  size_t pinned_bytes = 0;
+};
+
+int fl_set_error(fl_context *ctx, int code, const char *fmt, ...);
+int fl_scratch(fl_context *ctx, size_t bytes, void **out);
+int fl_pinned(fl_context *ctx, size_t bytes, void **out);
+
+#define FL_HIP(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fl_set_error((ctx), FL_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, \
+                          hipGetErrorString(e_));                                          \
+  } while (0)
+
+static inline size_t fl_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device-side table entries ------------------------------------------------------------
+// Offset of a feature's linear memory relative to the (level, modality) LM base of a frame.
+#define FL_MAX_LEVELS 4
+#define FL_MAX_MODALITIES 2
+#define FL_MAX_FEATURES 63
+
+struct FlScanHdr {       // one per (pyramid g, modality m) at the coarsest level
+  int32_t P;             // template_positions (linemod.cpp:1155); <= 0: nothing to add
+  int32_t off_begin;     // first entry in scan_offsets
+  int32_t n_pad;         // entries, padded to a multiple of 8 with the zero offset
+  int32_t nf;            // templ.features.size() (counts skipped features too)
+};
+struct FlFineFeat {      // one per feature at the finer levels
+  int16_t x, y;          // template-relative position (for the bounds test, linemod.cpp:1257)
+  uint32_t lmoff;        // label*stride + grid*WH + (y/T)*W + x/T
+};
+struct FlFineHdr {       // one per (pyramid g, level l < L-1, modality m)
+  int32_t feat_begin, feat_count;
+  int32_t width, height; // of this template (tp[start].width/height are taken from m == 0)
+};
+struct FlPyrInfo {       // one per pyramid g
+  int32_t class_idx, template_id;
+  int32_t off_x0, off_y0, width0, height0;   // template[0]: rect_model_raw (obj_reco_lmicp.cpp:129)
+  int32_t depth_slot;                        // index into the model-depth bank or -1
+  int32_t pad;
+};
+struct FlCand {          // a candidate / match in flight
+  int32_t x, y;
+  int32_t g;             // global pyramid index; -1 once filtered out
+  float sim;
+};
+
+struct FlLevelGeom {
+  int32_t w, h, T, W, H, WH;
+  uint32_t stride;       // bytes per label block
+  uint32_t zero_off;     // offset (within a modality's LM) of >= WH+16W+64 zero bytes
+  size_t quant_off[FL_MAX_MODALITIES];   // offsets inside a frame workspace
+  size_t lm_off[FL_MAX_MODALITIES];
+  size_t bgr_off;                        // colour image of this level
+};
+
+struct FlClass {
+  std::string id;
+  int n_pyramids = 0;
+  std::vector<fl_template> templates;
+  std::vector<fl_feature> features;
+  std::vector<float> poses;              // n_pyramids*13 or empty
+  int first_g = 0;                       // set at finalize
+  uint16_t *d_depths = nullptr;          // n_pyramids * dw*dh u16 (0.1 mm) or null
+  int dw = 0, dh = 0;
+};
+
+struct fl_detector {
+  fl_context *ctx = nullptr;
+  int M = 0, L = 0;
+  int T[FL_MAX_LEVELS] = {0};
+  std::vector<FlClass> classes;          // kept sorted by id
+  bool finalized = false;
+  int w0 = 0, h0 = 0, max_batch = 0, cap = 0;
+  int n_pyr = 0;
+  FlLevelGeom geom[FL_MAX_LEVELS];
+
+  // device tables
+  FlScanHdr *d_scan_hdr = nullptr;       // n_pyr * M
+  uint32_t *d_scan_off = nullptr;
+  FlFineHdr *d_fine_hdr = nullptr;       // n_pyr * (L-1) * M, index (g*(L-1)+l)*M+m
+  FlFineFeat *d_fine_feat = nullptr;
+  FlPyrInfo *d_pyr = nullptr;            // n_pyr
+  int *d_class_first = nullptr;          // first global pyramid index of each class
+  float *d_poses = nullptr;              // n_pyr * 13 (zeros when absent)
+  const uint16_t **d_depth_ptrs = nullptr; // n_pyr pointers to model depth (0.1mm) or null
+  int depth_w = 0, depth_h = 0;
+  int max_tw = 0, max_th = 0;            // largest template[0] width/height: bounds the ICP clouds
+
+  // per-frame workspace: one allocation, frame stride `ws_stride`
+  uint8_t *d_ws = nullptr;
+  size_t ws_stride = 0;
+  size_t off_bgr = 0, off_depth = 0, off_cand = 0, off_count = 0, off_keys = 0, off_match = 0;
+  size_t off_icp = 0, off_tmp = 0;
+  int n_pts_max = 0;
+  int last_batch = 0;
+  bool last_from_images = false;
+
+  // results
+  fl_recognition_result *d_results = nullptr;   // max_batch
+  fl_recognition_result *h_results = nullptr;   // pinned
+  // timing
+  hipEvent_t ev[10] = {nullptr};
+  fl_stage_times times;
+  bool have_times = false;
+  double scan_bytes_per_frame = 0;       // SURVEY 8(d) B_tmpl summed over the bank
+};
+
+// ---- stage launchers (defined in the per-domain .hip files) ---------------------------------
+// linemod
+int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *lm,
+                       size_t lm_stride, int n_frames, int w, int h, int T);
+int fl_launch_match_core(fl_detector *det, int n_frames, float threshold);
+// frontend
+int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t in_stride,
+                                     uint8_t *dst, size_t out_stride, int n_frames, int w, int h,
+                                     float weak_threshold);
+int fl_launch_quantized_normals(fl_context *ctx, const uint16_t *depth, size_t in_stride,
+                                uint8_t *dst, size_t out_stride, uint8_t *tmp, size_t tmp_stride,
+                                int n_frames, int w, int h, int distance_threshold,
+                                int difference_threshold);
+int fl_launch_pyrdown_bgr(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst,
+                          size_t out_stride, int n_frames, int w, int h);
+int fl_launch_resize_nn_half(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst,
+                             size_t out_stride, int n_frames, int w, int h);
+int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_t bgr_stride,
+                       const uint16_t *depth, size_t depth_stride);
+// icp
+size_t fl_icp_ws_bytes(int n_pts_max);
+int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K,
+                              const fl_recognition_params *p, const uint16_t *depth,
+                              size_t depth_stride);

@@ -1,0 +1,632 @@
+// fl_linemod.hip -- hand-written gfx950 kernels for the online matching half of
+// cup_linemod::Detector (reference: linemod/linemod.cpp:882-1577).
+//
+//   k_build_lm     spread + computeResponseMaps + linearize x8 fused        (:950-1088)
+//   k_scan         similarity + addSimilarities + coarse threshold          (:1130-1214, 1322-1338, 1483-1506)
+//   k_refine       similarityLocal + 16x16 argmax + filter, one level       (:1226-1300, 1509-1573)
+//   k_sort_unique  std::sort + std::unique of the surviving matches         (:1437-1439)
+//
+// Data layout in HBM (per frame, per level, per modality): the 8 linear memories
+//   LM[label 0..7][grid (y%T)*T + x%T][(y/T)*W + x/T]   + per-label zero pad
+// i.e. exactly the reference's "linearized" Mats laid back to back, so that the reference's
+// 1-D scan over template_positions (including its row wrap-around, quirk Q1, and its over-read
+// into the next grid row, Q2) is reproduced by plain linear addressing.
+// All integer work; the only float expressions are the reference's own score formulas, built
+// with -ffp-contract=off so each operator is one IEEE binary32 operation.
+#include "fl_internal.h"
+
+// ------------------------------------------------------------------------------------------
+// k_build_lm: one thread per (grid cell, linear position p); the 8 label bytes it produces go
+// to 8 coalesced byte streams.  Response of orientation `ori` to a spread byte b
+// (SIMILARITY_LUT of this fork, linemod.cpp:970): 4 if bit ori is set, else 2 if a
+// neighbouring orientation (+-1 mod 8) is set, else 1 if +-2 is set, else 0 -- evaluated with
+// an 8-bit rotate instead of the two 16-entry table look-ups (identical integers).
+__global__ __launch_bounds__(256) void k_build_lm(const uint8_t *__restrict__ quant, size_t quant_stride,
+                                                  uint8_t *__restrict__ lm, size_t lm_stride, int w, int h,
+                                                  int T, int W, int WH, uint32_t stride)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int gi = blockIdx.y;
+  const uint8_t *q = quant + (size_t)blockIdx.z * quant_stride;
+  uint8_t *out = lm + (size_t)blockIdx.z * lm_stride;
+  if (p >= WH) return;
+  const int gy = gi / T, gx = gi - gy * T;
+  const int yt = p / W, xt = p - yt * W;
+  const int y = yt * T + gy, x = xt * T + gx;
+  // spread (linemod.cpp:950-965): OR over the T x T window anchored at (y, x), clipped
+  unsigned b = 0;
+  const int rmax = min(T, h - y), cmax = min(T, w - x);
+  for (int r = 0; r < rmax; ++r) {
+    const uint8_t *row = q + (size_t)(y + r) * w + x;
+    for (int c = 0; c < cmax; ++c) b |= row[c];
+  }
+  const unsigned bb = b | (b << 8);           // rotate helper
+#pragma unroll
+  for (int ori = 0; ori < 8; ++ori) {
+    unsigned rot = (bb >> ori) & 0xFFu;
+    unsigned r = (rot & 1u) ? 4u : ((rot & 0x82u) ? 2u : ((rot & 0x44u) ? 1u : 0u));
+    out[(size_t)ori * stride + (size_t)gi * WH + p] = (uint8_t)r;
+  }
+}
+
+int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *lm,
+                       size_t lm_stride, int n_frames, int w, int h, int T)
+{
+  const int W = w / T, H = h / T, WH = W * H;
+  dim3 grid((WH + 255) / 256, T * T, n_frames);
+  hipLaunchKernelGGL(k_build_lm, grid, dim3(256), 0, ctx->stream, quant, quant_stride, lm, lm_stride, w, h, T, W, WH,
+                     (uint32_t)fl_lm_label_stride(w, h, T));
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan: one wavefront per (pyramid, 1024-position chunk, frame).  Lane i owns 16 consecutive
+// positions and keeps their u8 partial sums packed in four 32-bit registers per modality:
+// with <= 63 features of response <= 4 a byte never carries (63*4 = 252, linemod.cpp:1133-1137),
+// so one 32-bit add sums four positions.  Feature offsets are wave-uniform (scalar loads), padded
+// to a multiple of 8 with the offset of the zero pad so that 8 independent 16-byte loads are in
+// flight per step.  The linear memories (1.2 MB per frame at VGA/T=8) are shared by all
+// templates and are served from L2; the feature tables are the only per-template HBM stream.
+struct ScanArgs {
+  const FlScanHdr *hdr;
+  const uint32_t *offs;
+  uint8_t *ws;               // frame workspace base
+  size_t ws_stride;
+  size_t lm_off[FL_MAX_MODALITIES];
+  size_t off_count, off_cand;
+  int n_pyr, M, nchunks, W, WH, T, cap;
+  float threshold;
+  uint16_t *dbg;             // optional raw u16 maps of pyramids [dbg_first, dbg_first+dbg_count)
+  int dbg_first, dbg_count;
+};
+
+__device__ __forceinline__ uint4 ld16(const uint8_t *p)
+{
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);     // global_load_dwordx4, any byte alignment (unaligned access mode)
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_scan(ScanArgs a)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  if (item >= a.n_pyr * a.nchunks) return;
+  const int g = item / a.nchunks, chunk = item - g * a.nchunks;
+  const int frame = blockIdx.y;
+  uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
+  const int j0 = chunk * 1024 + lane * 16;
+
+  uint32_t tot[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tot[i] = 0;
+  int nf = 0;
+  for (int m = 0; m < a.M; ++m) {
+    const FlScanHdr h = a.hdr[g * a.M + m];
+    nf += h.nf;
+    if (j0 >= h.P) continue;
+    const uint8_t *lm = ws + a.lm_off[m] + j0;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const uint32_t *offs = a.offs + h.off_begin;
+    for (int k = 0; k < h.n_pad; k += 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld16(lm + offs[k + u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w; }
+    }
+    const uint32_t acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint32_t byte = (acc[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+      tot[i] += (j0 + i < h.P) ? byte : 0u;        // cells >= template_positions stay 0 (:1160)
+    }
+  }
+  if (a.dbg && g >= a.dbg_first && g < a.dbg_first + a.dbg_count) {
+    uint16_t *d = a.dbg + ((size_t)frame * a.dbg_count + (g - a.dbg_first)) * a.WH;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (j0 + i < a.WH) d[j0 + i] = (uint16_t)tot[i];
+  }
+  // coarse threshold (linemod.cpp:1483-1506), float expression evaluated as written
+  const int raw_threshold = (int)(2 * nf + (a.threshold / 100.f) * (2 * nf) + 0.5f);
+  uint32_t mx = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mx = max(mx, tot[i]);
+  if ((int)mx <= raw_threshold) return;
+  int *count = (int *)(ws + a.off_count);
+  FlCand *cand = (FlCand *)(ws + a.off_cand);
+  const int offset = a.T / 2 + (a.T % 2 - 1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int raw = (int)tot[i];
+    const int j = j0 + i;
+    if (raw > raw_threshold && j < a.WH) {
+      const int r = j / a.W, c = j - r * a.W;
+      const int idx = atomicAdd(count, 1);
+      if (idx < a.cap) {
+        FlCand cd;
+        cd.x = c * a.T + offset;
+        cd.y = r * a.T + offset;
+        cd.g = g;
+        cd.sim = (raw * 100.f) / (4 * nf) + 0.5f;                               // :1502
+        cand[idx] = cd;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_refine: one wavefront per candidate.  The 16x16 patch is held as 64 lanes x 4 packed bytes
+// (lane = row*4 + column group); each in-bounds feature costs one 4-byte load per lane.
+struct RefineArgs {
+  const FlFineHdr *hdr;
+  const FlFineFeat *feat;
+  uint8_t *ws;
+  size_t ws_stride;
+  size_t lm_off[FL_MAX_MODALITIES];
+  size_t off_count, off_cand;
+  int M, Lm1, level, w, h, T, W, cap;
+  float threshold;
+};
+
+__global__ __launch_bounds__(256) void k_refine(RefineArgs a)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.y;
+  uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
+  const int n = min(*(const int *)(ws + a.off_count), a.cap);
+  FlCand *cand = (FlCand *)(ws + a.off_cand);
+  const int row = lane >> 2, col4 = (lane & 3) * 4;
+  const int T = a.T, W = a.W;
+  const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+  for (int ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
+    FlCand cd = cand[ci];
+    const int g = __builtin_amdgcn_readfirstlane(cd.g);
+    if (g < 0) continue;
+    const FlFineHdr *hdr = a.hdr + ((size_t)g * a.Lm1 + a.level) * a.M;
+    const int max_x = a.w - hdr[0].width - border;                      // :1517-1518 (tp[start])
+    const int max_y = a.h - hdr[0].height - border;
+    int x = __builtin_amdgcn_readfirstlane(cd.x) * 2 + 1, y = __builtin_amdgcn_readfirstlane(cd.y) * 2 + 1;
+    x = max(x, border);
+    y = max(y, border);
+    x = min(x, max_x);
+    y = min(y, max_y);
+    const int offset_x = (x / T - 8) * T, offset_y = (y / T - 8) * T;   // C division (trunc), :1240
+    const int shift = (offset_y / T) * W + offset_x / T;
+    uint32_t tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;                    // u16 totals of 4 positions
+    int numFeatures = 0;
+    for (int m = 0; m < a.M; ++m) {
+      const FlFineHdr h = hdr[m];
+      numFeatures += h.feat_count;
+      const uint8_t *lm = ws + a.lm_off[m] + row * W + col4;
+      const FlFineFeat *ff = a.feat + h.feat_begin;
+      uint32_t acc = 0;
+      for (int k = 0; k < h.feat_count; ++k) {
+        const FlFineFeat f = ff[k];
+        const int fx = f.x + offset_x, fy = f.y + offset_y;
+        if (fx < 0 || fy < 0 || fx >= a.w || fy >= a.h) continue;       // :1257 (wave-uniform)
+        uint32_t v;
+        __builtin_memcpy(&v, lm + (uint32_t)(f.lmoff + (uint32_t)shift), 4);
+        acc += v;                                                       // 4 packed u8 adds
+      }
+      tot0 += acc & 0xFFu;
+      tot1 += (acc >> 8) & 0xFFu;
+      tot2 += (acc >> 16) & 0xFFu;
+      tot3 += acc >> 24;
+    }
+    // first strict maximum in row-major order (:1547-1562): key = score << 8 | (255 - pos)
+    const int pos = row * 16 + col4;
+    uint32_t key = (tot0 << 8) | (uint32_t)(255 - pos);
+    key = max(key, (tot1 << 8) | (uint32_t)(254 - pos));
+    key = max(key, (tot2 << 8) | (uint32_t)(253 - pos));
+    key = max(key, (tot3 << 8) | (uint32_t)(252 - pos));
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, s, 64));
+    const int best_score = (int)(key >> 8);
+    int best_r = -1, best_c = -1;                                       // Q4: all-zero patch
+    if (best_score > 0) {
+      const int bp = 255 - (int)(key & 0xFFu);
+      best_r = bp >> 4;
+      best_c = bp & 15;
+    }
+    if (lane == 0) {
+      cd.x = (x / T - 8 + best_c) * T + offset;                         // :1564-1566
+      cd.y = (y / T - 8 + best_r) * T + offset;
+      cd.sim = (best_score * 100.f) / (4 * numFeatures);
+      if (cd.sim < a.threshold) cd.g = -1;                              // MatchPredicate :1447
+      cand[ci] = cd;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sort_unique: one 1024-thread workgroup per frame.  128-bit keys, sorted descending:
+//   hi = similarity bits << 32 | (0x7FFFFFFF - template_id)     (Match::operator<, linemod.hpp:262)
+//   lo = (0xFFFF - class) << 32 | (0xFFFF - (y+32768)) << 16 | (0xFFFF - (x+32768))
+// lo only fixes the order std::sort leaves unspecified (Q5).  Bitonic network in LDS when the
+// padded count fits, otherwise in the frame's key scratch in HBM (same code, block-level sync).
+struct Key128 { unsigned long long hi, lo; };
+__device__ __forceinline__ bool key_gt(const Key128 &a, const Key128 &b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
+
+struct SortArgs {
+  const FlPyrInfo *pyr;
+  uint8_t *ws;
+  size_t ws_stride;
+  size_t off_count, off_cand, off_keys, off_match;
+  int cap;
+};
+
+#define FL_SORT_LDS_KEYS 2048
+
+template <bool IN_LDS>
+__device__ void bitonic_desc(Key128 *k, int n2)
+{
+  for (int size = 2; size <= n2; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const bool desc = ((i & size) == 0);
+        Key128 a = k[i], b = k[j];
+        if (key_gt(b, a) == desc) { k[i] = b; k[j] = a; }
+      }
+    }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sort_unique(SortArgs a)
+{
+  __shared__ Key128 lds_keys[FL_SORT_LDS_KEYS];
+  __shared__ int s_n, s_scan[1024], s_base;
+  const int frame = blockIdx.x;
+  uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
+  int *counters = (int *)(ws + a.off_count);      // [0] candidates, [1] matches out, [2] overflow flag
+  const int n_raw = *counters;
+  const int n = min(n_raw, a.cap);
+  const FlCand *cand = (const FlCand *)(ws + a.off_cand);
+  Key128 *gkeys = (Key128 *)(ws + a.off_keys);
+  fl_match *out = (fl_match *)(ws + a.off_match);
+  if (threadIdx.x == 0) { s_n = 0; s_base = 0; }
+  __syncthreads();
+  // gather live candidates (order irrelevant before the sort)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const FlCand c = cand[i];
+    if (c.g >= 0) {
+      const FlPyrInfo pi = a.pyr[c.g];
+      Key128 k;
+      k.hi = ((unsigned long long)__float_as_uint(c.sim) << 32) | (unsigned)(0x7FFFFFFF - pi.template_id);
+      k.lo = ((unsigned long long)(0xFFFF - pi.class_idx) << 32) | ((unsigned long long)(0xFFFF - (c.y + 32768)) << 16) |
+             (unsigned long long)(0xFFFF - (c.x + 32768));
+      const int slot = atomicAdd(&s_n, 1);
+      gkeys[slot] = k;
+    }
+  }
+  __syncthreads();
+  const int nl = s_n;
+  int n2 = 1;
+  while (n2 < nl) n2 <<= 1;
+  const Key128 zero = {0ull, 0ull};
+  Key128 *keys;
+  if (n2 <= FL_SORT_LDS_KEYS) {
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) lds_keys[i] = i < nl ? gkeys[i] : zero;
+    keys = lds_keys;
+    bitonic_desc<true>(keys, n2);
+  } else {
+    for (int i = nl + threadIdx.x; i < n2; i += blockDim.x) gkeys[i] = zero;
+    keys = gkeys;
+    bitonic_desc<false>(keys, n2);
+  }
+  // std::unique with Match::operator== (x, y, similarity, class; template_id ignored) + compaction
+  for (int base = 0; base < nl; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    int flag = 0;
+    Key128 k = zero;
+    if (i < nl) {
+      k = keys[i];
+      if (i == 0) flag = 1;
+      else {
+        const Key128 p = keys[i - 1];
+        flag = !((k.hi >> 32) == (p.hi >> 32) && k.lo == p.lo);
+      }
+    }
+    s_scan[threadIdx.x] = flag;
+    __syncthreads();
+    for (int d = 1; d < (int)blockDim.x; d <<= 1) {      // Hillis-Steele inclusive scan
+      int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+      __syncthreads();
+      s_scan[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int pos = s_base + s_scan[threadIdx.x] - flag;
+    if (flag) {
+      fl_match m;
+      m.similarity = __uint_as_float((unsigned)(k.hi >> 32));
+      m.template_id = 0x7FFFFFFF - (int)(k.hi & 0xFFFFFFFFu);
+      m.class_idx = 0xFFFF - (int)(k.lo >> 32);
+      m.y = (0xFFFF - (int)((k.lo >> 16) & 0xFFFF)) - 32768;
+      m.x = (0xFFFF - (int)(k.lo & 0xFFFF)) - 32768;
+      out[pos] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) s_base += s_scan[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    counters[1] = s_base;
+    counters[2] = n_raw > a.cap ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+static int launch_scan_refine_sort(fl_detector *det, int n_frames, float threshold, uint16_t *dbg, int dbg_first,
+                                   int dbg_count)
+{
+  fl_context *ctx = det->ctx;
+  const int L = det->L, M = det->M;
+  // zero the per-frame counters
+  FL_HIP(ctx, hipMemset2DAsync(det->d_ws + det->off_count, det->ws_stride, 0, 16, n_frames, ctx->stream));
+  {
+    const FlLevelGeom &g = det->geom[L - 1];
+    ScanArgs a;
+    a.hdr = det->d_scan_hdr;
+    a.offs = det->d_scan_off;
+    a.ws = det->d_ws;
+    a.ws_stride = det->ws_stride;
+    for (int m = 0; m < FL_MAX_MODALITIES; ++m) a.lm_off[m] = g.lm_off[m < M ? m : 0];
+    a.off_count = det->off_count;
+    a.off_cand = det->off_cand;
+    a.n_pyr = det->n_pyr;
+    a.M = M;
+    a.nchunks = (g.WH + 1023) / 1024;
+    a.W = g.W;
+    a.WH = g.WH;
+    a.T = g.T;
+    a.cap = det->cap;
+    a.threshold = threshold;
+    a.dbg = dbg;
+    a.dbg_first = dbg_first;
+    a.dbg_count = dbg_count;
+    const int items = det->n_pyr * a.nchunks;
+    if (items > 0) {
+      dim3 grid((items + 3) / 4, n_frames);
+      hipLaunchKernelGGL(k_scan, grid, dim3(256), 0, ctx->stream, a);
+      FL_HIP(ctx, hipGetLastError());
+    }
+  }
+  if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[3], ctx->stream));
+  for (int l = L - 2; l >= 0; --l) {
+    const FlLevelGeom &g = det->geom[l];
+    RefineArgs a;
+    a.hdr = det->d_fine_hdr;
+    a.feat = det->d_fine_feat;
+    a.ws = det->d_ws;
+    a.ws_stride = det->ws_stride;
+    for (int m = 0; m < FL_MAX_MODALITIES; ++m) a.lm_off[m] = g.lm_off[m < M ? m : 0];
+    a.off_count = det->off_count;
+    a.off_cand = det->off_cand;
+    a.M = M;
+    a.Lm1 = L - 1;
+    a.level = l;
+    a.w = g.w;
+    a.h = g.h;
+    a.T = g.T;
+    a.W = g.W;
+    a.cap = det->cap;
+    a.threshold = threshold;
+    dim3 grid(n_frames >= 64 ? 32 : 256, n_frames);
+    hipLaunchKernelGGL(k_refine, grid, dim3(256), 0, ctx->stream, a);
+    FL_HIP(ctx, hipGetLastError());
+  }
+  if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[4], ctx->stream));
+  {
+    SortArgs a;
+    a.pyr = det->d_pyr;
+    a.ws = det->d_ws;
+    a.ws_stride = det->ws_stride;
+    a.off_count = det->off_count;
+    a.off_cand = det->off_cand;
+    a.off_keys = det->off_keys;
+    a.off_match = det->off_match;
+    a.cap = det->cap;
+    hipLaunchKernelGGL(k_sort_unique, dim3(n_frames), dim3(1024), 0, ctx->stream, a);
+    FL_HIP(ctx, hipGetLastError());
+  }
+  if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[5], ctx->stream));
+  return FL_OK;
+}
+
+// spread/response/linearize for all levels and modalities of n_frames frames, then the match core
+int fl_launch_match_core(fl_detector *det, int n_frames, float threshold)
+{
+  fl_context *ctx = det->ctx;
+  for (int l = 0; l < det->L; ++l) {
+    const FlLevelGeom &g = det->geom[l];
+    for (int m = 0; m < det->M; ++m) {
+      int rc = fl_launch_build_lm(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.lm_off[m],
+                                  det->ws_stride, n_frames, g.w, g.h, g.T);
+      if (rc) return rc;
+    }
+  }
+  if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[2], ctx->stream));
+  return launch_scan_refine_sort(det, n_frames, threshold, nullptr, 0, 0);
+}
+
+static int read_matches(fl_detector *det, int frame, fl_match *out, int cap, int *n_total)
+{
+  fl_context *ctx = det->ctx;
+  int counters[4];
+  uint8_t *ws = det->d_ws + (size_t)frame * det->ws_stride;
+  FL_HIP(ctx, hipMemcpyAsync(counters, ws + det->off_count, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (counters[2]) return fl_set_error(ctx, FL_ERR_OVERFLOW, "more than %d candidates in one frame", det->cap);
+  if (n_total) *n_total = counters[1];
+  int n = counters[1] < cap ? counters[1] : cap;
+  if (n > 0 && out) {
+    FL_HIP(ctx, hipMemcpyAsync(out, ws + det->off_match, sizeof(fl_match) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return FL_OK;
+}
+
+extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quantized, int mem, float threshold,
+                                  fl_match *out, int cap, int *n_total)
+{
+  if (!det || !quantized || cap < 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  for (int l = 0; l < det->L; ++l)
+    for (int m = 0; m < det->M; ++m) {
+      const FlLevelGeom &g = det->geom[l];
+      FL_HIP(ctx, hipMemcpyAsync(det->d_ws + g.quant_off[m], quantized[l * det->M + m], (size_t)g.w * g.h,
+                                 mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    }
+  det->have_times = false;
+  int rc = fl_launch_match_core(det, 1, threshold);
+  if (rc) return rc;
+  det->last_batch = 1;
+  det->last_from_images = false;
+  return read_matches(det, 0, out, cap, n_total);
+}
+
+extern "C" int fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, float threshold,
+                        fl_match *out, int cap, int *n_total)
+{
+  if (!det || !bgr || cap < 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
+  if (det->M == 2 && !depth) return fl_set_error(ctx, FL_ERR_INVALID, "sources.size() != modalities.size() (linemod.cpp:1364)");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_bgr, bgr, (size_t)det->w0 * det->h0 * 3, kind, ctx->stream));
+  if (det->M == 2)
+    FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_depth, depth, (size_t)det->w0 * det->h0 * 2, kind, ctx->stream));
+  det->have_times = false;
+  int rc = fl_launch_frontend(det, 1, det->d_ws + det->off_bgr, det->ws_stride,
+                              (const uint16_t *)(det->d_ws + det->off_depth), det->ws_stride);
+  if (rc) return rc;
+  rc = fl_launch_match_core(det, 1, threshold);
+  if (rc) return rc;
+  det->last_batch = 1;
+  det->last_from_images = true;
+  return read_matches(det, 0, out, cap, n_total);
+}
+
+extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16_t *out)
+{
+  if (!det || !out || first < 0 || count <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || det->last_batch < 1) return fl_set_error(ctx, FL_ERR_STATE, "no frame matched yet");
+  if (first + count > det->n_pyr) return fl_set_error(ctx, FL_ERR_INVALID, "pyramid range");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const FlLevelGeom &g = det->geom[det->L - 1];
+  size_t bytes = (size_t)count * g.WH * sizeof(uint16_t);
+  void *d = nullptr;
+  int rc = fl_scratch(ctx, bytes, &d);
+  if (rc) return rc;
+  FL_HIP(ctx, hipMemsetAsync(d, 0, bytes, ctx->stream));
+  // re-run the scan on frame 0's resident linear memories with the debug tap on; threshold 200%
+  // keeps the candidate buffer untouched in practice (counters are reset by the launcher)
+  det->have_times = false;
+  rc = launch_scan_refine_sort(det, 1, 200.0f, (uint16_t *)d, first, count);
+  if (rc) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FL_OK;
+}
+
+extern "C" int fl_last_quantized(fl_detector *det, uint8_t *out)
+{
+  if (!det || !out) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || det->last_batch < 1) return fl_set_error(ctx, FL_ERR_STATE, "no frame matched yet");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  for (int l = 0; l < det->L; ++l)
+    for (int m = 0; m < det->M; ++m) {
+      const FlLevelGeom &g = det->geom[l];
+      FL_HIP(ctx, hipMemcpyAsync(out, det->d_ws + g.quant_off[m], (size_t)g.w * g.h, hipMemcpyDeviceToHost, ctx->stream));
+      out += (size_t)g.w * g.h;
+    }
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FL_OK;
+}
+
+extern "C" int fl_build_linear_memories(fl_context *ctx, const uint8_t *quantized, int w, int h, int T, uint8_t *out,
+                                        int mem)
+{
+  if (!ctx || !quantized || !out || w <= 0 || h <= 0 || T < 1 || T > 16) return FL_ERR_INVALID;
+  if (w % T || h % T) return fl_set_error(ctx, FL_ERR_ASSERT, "rows/cols %% T != 0 (CV_Assert linemod.cpp:1062-1063)");
+  if ((w * h) % 16) return fl_set_error(ctx, FL_ERR_ASSERT, "rows*cols %% 16 != 0 (CV_Assert linemod.cpp:981)");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nq = (size_t)w * h, nlm = 8 * fl_lm_label_stride(w, h, T);
+  const uint8_t *dq = quantized;
+  uint8_t *dlm = out;
+  if (mem == FL_MEM_HOST) {
+    void *s = nullptr;
+    int rc = fl_scratch(ctx, fl_align(nq, 256) + nlm, &s);
+    if (rc) return rc;
+    FL_HIP(ctx, hipMemcpyAsync(s, quantized, nq, hipMemcpyHostToDevice, ctx->stream));
+    dq = (const uint8_t *)s;
+    dlm = (uint8_t *)s + fl_align(nq, 256);
+  }
+  FL_HIP(ctx, hipMemsetAsync(dlm, 0, nlm, ctx->stream));       // the zero pads
+  int rc = fl_launch_build_lm(ctx, dq, 0, dlm, 0, 1, w, h, T);
+  if (rc) return rc;
+  if (mem == FL_MEM_HOST) {
+    FL_HIP(ctx, hipMemcpyAsync(out, dlm, nlm, hipMemcpyDeviceToHost, ctx->stream));
+    FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return FL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU helpers: fixed-size top-k export for the RCCL all-gather, and the host merge
+__global__ void k_export_topk(const uint8_t *ws, size_t off_count, size_t off_match, int k, int tid_base, fl_match *out)
+{
+  const int n = ((const int *)(ws + off_count))[1];
+  const fl_match *m = (const fl_match *)(ws + off_match);
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    fl_match r;
+    if (i < n) { r = m[i]; r.template_id += tid_base; }
+    else { r.x = r.y = 0; r.similarity = 0.f; r.class_idx = -1; r.template_id = -1; }
+    out[i] = r;
+  }
+}
+
+extern "C" int fl_export_topk(fl_detector *det, int frame, int k, int template_id_base, void *dev_out)
+{
+  if (!det || !dev_out || k <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || frame < 0 || frame >= det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "frame");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_export_topk, dim3(1), dim3(256), 0, ctx->stream, det->d_ws + (size_t)frame * det->ws_stride,
+                     det->off_count, det->off_match, k, template_id_base, (fl_match *)dev_out);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+#include <algorithm>
+extern "C" int fl_merge_topk(const fl_match *gathered, int n_records, fl_match *out, int cap)
+{
+  if (!gathered || !out || n_records < 0 || cap < 0) return FL_ERR_INVALID;
+  std::vector<fl_match> v;
+  for (int i = 0; i < n_records; ++i)
+    if (gathered[i].template_id >= 0) v.push_back(gathered[i]);
+  std::sort(v.begin(), v.end(), [](const fl_match &a, const fl_match &b) {
+    if (a.similarity != b.similarity) return a.similarity > b.similarity;
+    if (a.template_id != b.template_id) return a.template_id < b.template_id;
+    if (a.class_idx != b.class_idx) return a.class_idx < b.class_idx;
+    if (a.y != b.y) return a.y < b.y;
+    return a.x < b.x;
+  });
+  auto eq = [](const fl_match &a, const fl_match &b) {
+    return a.x == b.x && a.y == b.y && a.similarity == b.similarity && a.class_idx == b.class_idx;
+  };
+  v.erase(std::unique(v.begin(), v.end(), eq), v.end());
+  int n = (int)std::min<size_t>(v.size(), (size_t)cap);
+  for (int i = 0; i < n; ++i) out[i] = v[i];
+  return n;
+}

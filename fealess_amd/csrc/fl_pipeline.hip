@@ -1,0 +1,118 @@
+// fl_pipeline.hip -- CObjRecoLmICP::Recognition (CadReco/obj_reco_lmicp.cpp:86-204) for a batch
+// of frames: quantise -> linear memories -> scan -> refine -> sort/unique -> (device-side
+// hand-over of matches[0]) -> crop back-projection -> ICP -> 4x4 pose, queued back to back on
+// one HIP stream with no host synchronisation in between.  Every kernel is launched over the
+// whole batch (grid.z / grid.y / one workgroup per frame), so the launch count per batch is
+// constant (about a dozen) whatever the number of frames.
+#include "fl_internal.h"
+#include <string.h>
+
+static bool uniform_stride(const void *const *ptrs, int n, size_t min_bytes, size_t *stride)
+{
+  if (n == 1) { *stride = 0; return true; }
+  const uint8_t *p0 = (const uint8_t *)ptrs[0], *p1 = (const uint8_t *)ptrs[1];
+  if (p1 < p0 + min_bytes) return false;
+  const size_t s = (size_t)(p1 - p0);
+  for (int i = 2; i < n; ++i)
+    if ((const uint8_t *)ptrs[i] != p0 + s * (size_t)i) return false;
+  *stride = s;
+  return true;
+}
+
+extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr,
+                                   const uint16_t *const *depth, int mem, const fl_intrinsics *K,
+                                   const fl_recognition_params *params)
+{
+  if (!det || !bgr || !K || !params || n_frames <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
+  if (n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames %d > max_batch %d", n_frames, det->max_batch);
+  if (det->M == 2 && !depth) return fl_set_error(ctx, FL_ERR_INVALID, "depth frames required (2 modalities)");
+  // PrepareInputData (obj_reco_lmicp.cpp:216-259): image size must equal the intrinsics' size
+  if (K->width != det->w0 || K->height != det->h0)
+    return fl_set_error(ctx, FL_ERR_INVALID, "intrinsics are %dx%d, detector finalized for %dx%d", K->width, K->height,
+                        det->w0, det->h0);
+  for (int i = 0; i < n_frames; ++i)
+    if (!bgr[i] || (det->M == 2 && !depth[i])) return fl_set_error(ctx, FL_ERR_INVALID, "frame %d: null pData (CheckTImage)", i);
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+
+  const size_t bgr_bytes = (size_t)det->w0 * det->h0 * 3, depth_bytes = (size_t)det->w0 * det->h0 * 2;
+  const uint8_t *bgr_base = det->d_ws + det->off_bgr;
+  const uint16_t *depth_base = (const uint16_t *)(det->d_ws + det->off_depth);
+  size_t bgr_stride = det->ws_stride, depth_stride = det->ws_stride;
+  size_t s1 = 0, s2 = 0;
+  if (mem == FL_MEM_DEVICE && uniform_stride((const void *const *)bgr, n_frames, bgr_bytes, &s1) &&
+      (det->M < 2 || (uniform_stride((const void *const *)depth, n_frames, depth_bytes, &s2) && s2 % 2 == 0))) {
+    // frames already in HBM at a regular pitch: read them in place
+    bgr_base = bgr[0];
+    bgr_stride = s1;
+    if (det->M == 2) { depth_base = depth[0]; depth_stride = s2; }
+  } else {
+    const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int i = 0; i < n_frames; ++i) {
+      uint8_t *ws = det->d_ws + (size_t)i * det->ws_stride;
+      FL_HIP(ctx, hipMemcpyAsync(ws + det->off_bgr, bgr[i], bgr_bytes, kind, ctx->stream));
+      if (det->M == 2) FL_HIP(ctx, hipMemcpyAsync(ws + det->off_depth, depth[i], depth_bytes, kind, ctx->stream));
+    }
+  }
+  det->have_times = true;
+  FL_HIP(ctx, hipEventRecord(det->ev[0], ctx->stream));
+  int rc = fl_launch_frontend(det, n_frames, bgr_base, bgr_stride, depth_base, depth_stride);
+  if (rc) return rc;
+  rc = fl_launch_match_core(det, n_frames, params->matching_threshold);
+  if (rc) return rc;
+  FL_HIP(ctx, hipMemsetAsync(det->d_results, 0, sizeof(fl_recognition_result) * (size_t)n_frames, ctx->stream));
+  rc = fl_launch_detection_batch(det, n_frames, K, params, depth_base, depth_stride);
+  if (rc) return rc;
+  FL_HIP(ctx, hipEventRecord(det->ev[6], ctx->stream));
+  FL_HIP(ctx, hipMemcpyAsync(det->h_results, det->d_results, sizeof(fl_recognition_result) * (size_t)n_frames,
+                             hipMemcpyDeviceToHost, ctx->stream));
+  det->last_batch = n_frames;
+  det->last_from_images = true;
+  return FL_OK;
+}
+
+extern "C" int fl_recognize_collect(fl_detector *det, int n_frames, fl_recognition_result *results)
+{
+  if (!det || !results || n_frames <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || n_frames > det->last_batch) return fl_set_error(ctx, FL_ERR_STATE, "nothing submitted");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(results, det->h_results, sizeof(fl_recognition_result) * (size_t)n_frames);
+  if (det->have_times) {
+    fl_stage_times &t = det->times;
+    memset(&t, 0, sizeof(t));
+    float ms = 0;
+    auto el = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, det->ev[a], det->ev[b]); return ms; };
+    t.frontend_ms = el(0, 1);
+    t.linmem_ms = el(1, 2);
+    t.scan_ms = el(2, 3);
+    t.refine_ms = el(3, 4);
+    t.sort_ms = el(4, 5);
+    t.icp_ms = el(5, 6);
+    t.total_ms = el(0, 6);
+    t.backproject_ms = 0;                 // fused into the per-frame ICP workgroup
+    t.icp_launches = 1;
+    for (int i = 0; i < n_frames; ++i) t.icp_iters_total += results[i].found ? results[i].det.icp.iters : 0;
+    t.scan_algorithmic_bytes = det->scan_bytes_per_frame * n_frames;
+    det->have_times = false;
+  }
+  return FL_OK;
+}
+
+extern "C" int fl_recognize_batch(fl_detector *det, int n_frames, const uint8_t *const *bgr,
+                                  const uint16_t *const *depth, int mem, const fl_intrinsics *K,
+                                  const fl_recognition_params *params, fl_recognition_result *results)
+{
+  int rc = fl_recognize_submit(det, n_frames, bgr, depth, mem, K, params);
+  if (rc) return rc;
+  return fl_recognize_collect(det, n_frames, results);
+}
+
+extern "C" int fl_last_stage_times(fl_detector *det, fl_stage_times *out)
+{
+  if (!det || !out) return FL_ERR_INVALID;
+  *out = det->times;
+  return FL_OK;
+}

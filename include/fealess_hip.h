@@ -1,0 +1,222 @@
+/*
+ * fealess_hip.h -- C ABI of libfealess_hip.so: the MI355X (gfx950) implementation of the
+ * rlvc/FEALESS hot path (LINEMOD detection + depth back-projection + ICP refinement).
+ *
+ * The reference has no FFI of its own: its boundary is the C++ surface of
+ * CadReco/obj_reco_temp.h, CadReco/obj_reco_lmicp.h, linemod/linemod.hpp, ICP/ICP.h,
+ * ICP/detection.h and ICP/depth_to_3d.h.  Every entry point below names the reference
+ * function it replaces (paths relative to the reference root).  The C++ adapter in
+ * fealess_amd/cadreco/ re-exposes the reference's own class surface on top of this ABI
+ * (see INTEGRATION.md).
+ *
+ * Conventions: plain pointers and sizes only; no exceptions cross the ABI; every function
+ * returns FL_OK (0) or a negative fl_status; fl_last_error() gives the text.  A context is
+ * bound to one HIP device; calls on one context must be serialised by the caller (the
+ * reference's CObjRecoLmICP is not thread-safe either, obj_reco_lmicp.h:37-51).  Work is queued
+ * on the context's stream; functions that return results through host pointers synchronise
+ * that stream before returning, functions that write device pointers do not.
+ * There is NO CPU fallback: without a HIP device fl_context_create fails.
+ */
+#ifndef FEALESS_HIP_H
+#define FEALESS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_ABI_VERSION 1
+
+typedef enum {
+  FL_OK = 0,
+  FL_ERR_INVALID = -1,   /* bad argument (the reference returns ERROR_INVALID_PARAM / -1)       */
+  FL_ERR_HIP = -2,       /* a HIP runtime call failed                                           */
+  FL_ERR_ASSERT = -3,    /* the reference would hit a CV_Assert / cv::Exception here            */
+  FL_ERR_OVERFLOW = -4,  /* a fixed-capacity device buffer overflowed (see fl_detector_limits)  */
+  FL_ERR_NO_DEVICE = -5,
+  FL_ERR_STATE = -6      /* call order violated (e.g. matching before fl_detector_finalize)     */
+} fl_status;
+
+typedef enum { FL_MEM_HOST = 0, FL_MEM_DEVICE = 1 } fl_mem;
+
+/* ICP accumulation modes.
+ *   FL_ICP_PARITY : the 15 centroid/covariance sums and the distance sum are accumulated as
+ *                   sequential float32 chains in the reference's order (one lane per scalar),
+ *                   so results are bit-identical to the reference's arithmetic (ICP.cpp:8-25,
+ *                   731-735, 68-111).  Default.
+ *   FL_ICP_FAST   : the same sums as parallel fp64 tree reductions rounded once to float32
+ *                   (more accurate than the reference, not bit-identical to it).            */
+typedef enum { FL_ICP_PARITY = 0, FL_ICP_FAST = 1 } fl_icp_mode;
+
+typedef struct fl_context fl_context;
+typedef struct fl_detector fl_detector;
+
+/* linemod/linemod.hpp:32-43 (Feature), :47-58 (Template), :253-281 (Match) */
+typedef struct { int32_t x, y, label; } fl_feature;
+typedef struct {
+  int32_t width, height, offset_x, offset_y, pyramid_level;
+  int32_t feat_begin, feat_count;      /* range in the flat feature array handed over with it */
+} fl_template;
+typedef struct {
+  int32_t x, y;
+  float   similarity;
+  int32_t class_idx;                   /* index of class_id in std::map (sorted) order */
+  int32_t template_id;                 /* class-local id, as in the reference */
+} fl_match;
+
+/* CadReco/lotus_common.h:41-50 (TCamIntrinsicParam, without the unused distortion vector) */
+typedef struct { int32_t width, height; double fx, fy, cx, cy; } fl_intrinsics;
+
+/* result of icpCloudToCloud_Ex (ICP/ICP.cpp:617-809) */
+typedef struct {
+  float   R[9], T[3];
+  float   dist_mean;                   /* the function's return value (-1 if < 3 points) */
+  float   px_ratio;
+  int32_t iters;                       /* value of `iter` on exit */
+  int32_t n_corr_last;
+} fl_icp_result;
+
+/* result of detection() (ICP/detection.cpp:11-254) */
+typedef struct {
+  float   R_final[9], T_final[3];
+  fl_icp_result icp;
+  int32_t n_points;
+  int32_t status;                      /* FL_OK or FL_ERR_ASSERT (rect outside the image, Q10) */
+} fl_detection_result;
+
+/* result of CObjRecoLmICP::Recognition (CadReco/obj_reco_lmicp.cpp:86-204) for one frame */
+typedef struct {
+  int32_t status;                      /* FL_OK, or the error Recognition would return */
+  int32_t found;                       /* 0: vtResult empty; 1: one TObjRecoResult */
+  int32_t n_matches;                   /* matches.size() after sort/unique */
+  fl_match best;                       /* matches[0] */
+  float   pose[16];                    /* TObjRecoResult::tWorld2Cam, row-major 4x4 */
+  fl_detection_result det;
+} fl_recognition_result;
+
+typedef struct {
+  float   matching_threshold;          /* m_matching_threshold, default 75 (obj_reco_lmicp.cpp:52) */
+  int32_t icp_it_thr;                  /* default 10 (:53) */
+  float   dist_mean_thr;               /* default 0.5 (:54) */
+  float   dist_diff_thr;               /* default 0.01 (:55) */
+  int32_t icp_mode;                    /* fl_icp_mode */
+} fl_recognition_params;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int  fl_abi_version(void);
+int  fl_context_create(int device, fl_context **out);
+void fl_context_destroy(fl_context *ctx);
+const char *fl_last_error(const fl_context *ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL restores the context's own */
+int  fl_context_set_stream(fl_context *ctx, void *hip_stream);
+int  fl_context_synchronize(fl_context *ctx);
+
+/* ---- detector = cup_linemod::Detector state resident in HBM -------------------------------- */
+/* Detector::Detector(modalities, T_pyramid) (linemod.cpp:1348-1354). modalities is 1 or 2:
+ * index 0 = ColorGradient, 1 = DepthNormal (getDefaultLINEMOD, linemod.cpp:1829-1835). */
+int  fl_detector_create(fl_context *ctx, int modalities, int levels, const int *T_at_level,
+                        fl_detector **out);
+void fl_detector_destroy(fl_detector *det);
+/* Detector::addSyntheticTemplate x n (linemod.cpp:1636-1642) + addPoseInfo (:1617-1622):
+ * append a class of n_pyramids template pyramids, each levels*modalities fl_template ordered
+ * [l*modalities + m].  poses13 (n_pyramids*13 floats, may be NULL) is the row-major 3x4 pose +
+ * distance side table.  Classes are kept in std::map order of class_id. */
+int  fl_detector_add_class(fl_detector *det, const char *class_id, int n_pyramids,
+                           const fl_template *templates, const fl_feature *features,
+                           int n_features, const float *poses13);
+/* The per-template depth renders CObjRecoLmICP reads from <dir>/depth/<template_id>.png on
+ * every frame (obj_reco_lmicp.cpp:156-157): uploaded once, w*h u16 in 0.1 mm each, for the
+ * pyramids [first, first+count) of class class_idx.  src may be host or device memory. */
+int  fl_detector_set_model_depths(fl_detector *det, int class_idx, int first, int count,
+                                  const uint16_t *depth_01mm, int w, int h, int mem);
+/* Freeze the bank for frames of w0 x h0 and at most max_batch frames per call; uploads the
+ * flattened feature tables and allocates every per-frame workspace in HBM.  max_candidates is
+ * the per-frame capacity of the candidate / match buffers (0 = default 65536). */
+int  fl_detector_finalize(fl_detector *det, int w0, int h0, int max_batch, int max_candidates);
+int  fl_detector_num_templates(const fl_detector *det);     /* Detector::numTemplates() :1652 */
+int  fl_detector_num_classes(const fl_detector *det);
+
+/* ---- stage entry points (each is the drop-in for one reference function) ------------------- */
+/* quantizedOrientations + hysteresisGradient (linemod.cpp:230-385): bgr w*h*3 u8 -> w*h u8 */
+int  fl_quantized_orientations(fl_context *ctx, const uint8_t *bgr, int w, int h,
+                               float weak_threshold, uint8_t *dst, int mem);
+/* quantizedNormals incl. medianBlur (linemod.cpp:595-685): depth w*h u16 (mm) -> w*h u8 */
+int  fl_quantized_normals(fl_context *ctx, const uint16_t *depth, int w, int h,
+                          int distance_threshold, int difference_threshold, uint8_t *dst, int mem);
+/* cv::pyrDown on the colour image (linemod.cpp:443): w*h*3 -> (w/2)*(h/2)*3 */
+int  fl_pyrdown_bgr(fl_context *ctx, const uint8_t *src, int w, int h, uint8_t *dst, int mem);
+/* spread + computeResponseMaps + linearize x8 (linemod.cpp:950-1088) for one quantized image:
+ * out = 8 * fl_lm_label_stride(w,h,T) bytes, layout [label][T*T grid][(w/T)*(h/T)] + zero pad */
+size_t fl_lm_label_stride(int w, int h, int T);
+int  fl_build_linear_memories(fl_context *ctx, const uint8_t *quantized, int w, int h, int T,
+                              uint8_t *out, int mem);
+/* cup_d2pc::depthTo3d, CV_16UC1 depth (ICP/depth_to_3d.cpp:190-221): out w*h*3 f32 (metres) */
+int  fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int h, double fx, double fy,
+                    double cx, double cy, float *out, int mem);
+/* icpCloudToCloud_Ex (ICP/ICP.cpp:617-809): clouds are n*3 f32 (mm). res is host memory. */
+int  fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model,
+            int icp_it_thr, float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem,
+            fl_icp_result *res);
+/* detection() (ICP/detection.cpp:11-254): two w*h u16 depth images in mm. res is host memory. */
+int  fl_detection(fl_context *ctx, const uint16_t *model_depth, const uint16_t *scene_depth,
+                  int w, int h, const fl_intrinsics *K, const int rect_model[4],
+                  const int rect_ref[4], int icp_it_thr, float dist_mean_thr, float dist_diff_thr,
+                  const float r_match[9], const float t_match[3], int icp_mode, int mem,
+                  fl_detection_result *res);
+
+/* ---- Detector::match (linemod.cpp:1356-1441) ------------------------------------------------ */
+/* From caller-supplied quantized images (what Modality::process + quantize would return):
+ * quantized[l*modalities + m] is (w0>>l)*(h0>>l) u8.  out/n_total are host memory; matches come
+ * back sorted (similarity desc, template_id asc, then class, y, x asc -- one valid outcome of
+ * the reference's unstable std::sort) and de-duplicated as std::unique with Match::operator==. */
+int  fl_match_quantized(fl_detector *det, const uint8_t *const *quantized, int mem,
+                        float threshold, fl_match *out, int cap, int *n_total);
+/* From a BGR8 + depth16 frame with the default modality parameters (linemod.cpp:515-519,827-832) */
+int  fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem,
+              float threshold, fl_match *out, int cap, int *n_total);
+/* similarity + addSimilarities (linemod.cpp:1130-1214,1322-1338) for pyramids [first,first+count)
+ * at the coarsest level of the frame last passed to fl_match_*: out = count * (W_T*H_T) u16 (host) */
+int  fl_similarity_maps(fl_detector *det, int first, int count, uint16_t *out);
+/* the quantized images of the frame last passed to fl_match (Detector::match's optional
+ * quantized_images output, linemod.cpp:1411-1412): levels*modalities images back to back (host) */
+int  fl_last_quantized(fl_detector *det, uint8_t *out);
+
+/* ---- CObjRecoLmICP::Recognition (CadReco/obj_reco_lmicp.cpp:86-204), batched ---------------- */
+/* n_frames frames of w0 x h0 (already 640 wide), all stages on the GPU with
+ * no host round trip between LINEMOD and ICP.  bgr[i], depth[i] are host or device pointers
+ * (all the same kind).  results is host memory.  Frames are independent; results[i] equals what
+ * Recognition() returns for frame i. */
+int  fl_recognize_batch(fl_detector *det, int n_frames, const uint8_t *const *bgr,
+                        const uint16_t *const *depth, int mem, const fl_intrinsics *K,
+                        const fl_recognition_params *params, fl_recognition_result *results);
+/* same, but only queues the work on the context's stream; fl_recognize_collect() waits and
+ * copies the results out.  Lets the caller overlap two contexts / batches. */
+int  fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr,
+                         const uint16_t *const *depth, int mem, const fl_intrinsics *K,
+                         const fl_recognition_params *params);
+int  fl_recognize_collect(fl_detector *det, int n_frames, fl_recognition_result *results);
+
+/* ---- multi-GPU support: top-k records for the all-gather ------------------------------------ */
+/* After fl_match_frame / fl_recognize_submit: copy frame `frame`'s first k sorted matches into a
+ * device buffer (k * sizeof(fl_match) bytes, padded with template_id = -1) for an RCCL
+ * all-gather by the caller; template ids are offset by template_id_base (the shard's first
+ * global id).  Queued on the context's stream, no synchronisation. */
+int  fl_export_topk(fl_detector *det, int frame, int k, int template_id_base, void *dev_out);
+/* merge n_ranks*k gathered records (host) exactly as one Detector::match over the union would
+ * order them; returns the number written to out (<= cap). */
+int  fl_merge_topk(const fl_match *gathered, int n_records, fl_match *out, int cap);
+
+/* per-stage device time (ms) of the last fl_recognize_* call, by stage index; for bench.py */
+typedef struct {
+  float frontend_ms, linmem_ms, scan_ms, refine_ms, sort_ms, backproject_ms, icp_ms, total_ms;
+  int32_t icp_iters_total, icp_launches;
+  double scan_algorithmic_bytes;
+} fl_stage_times;
+int  fl_last_stage_times(fl_detector *det, fl_stage_times *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEALESS_HIP_H */

@@ -1,0 +1,78 @@
+"""GPU parity: quantisation front-end kernels vs the oracle, bit-exact (integer stages exactly,
+float stages operator by operator; OpenCV itself is unavailable -> parity unpinned)."""
+import numpy as np
+import pytest
+
+from fealess_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, w=640, h=480):
+    R, t = synth.object_pose(tx=20.0 * (seed % 3 - 1), ty=-10.0, tz=640.0 + 10 * seed, yaw=0.2 * seed)
+    return synth.render(w, h, R, t, seed=seed)
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 1), (320, 240, 2), (1280, 720, 3), (97, 61, 4), (33, 18, 5)])
+def test_quantized_orientations_bit_exact(ctx, oracle, w, h, seed):
+    if seed <= 3:
+        _, bgr, _ = _scene(seed, w, h)
+    else:
+        bgr = np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = ctx.quantized_orientations(bgr, 10.0)
+    exp = oracle.quantized_orientations(bgr, 10.0)
+    assert np.array_equal(got, exp), int((got != exp).sum())
+    if seed <= 3:
+        assert (exp != 0).sum() > 500          # not vacuous
+
+
+def test_quantized_orientations_noise_image(ctx, oracle):
+    bgr = np.random.default_rng(9).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    assert np.array_equal(ctx.quantized_orientations(bgr, 10.0), oracle.quantized_orientations(bgr, 10.0))
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 1), (1280, 720, 2), (64, 48, 3), (23, 17, 4)])
+def test_quantized_normals_bit_exact(ctx, oracle, w, h, seed):
+    if seed <= 2:
+        depth, _, _ = _scene(seed, w, h)
+    else:
+        depth = (600 + np.random.default_rng(seed).integers(0, 60, (h, w))).astype(np.uint16)
+    depth = depth.copy()
+    depth[5:9, 7:15] = 0                       # sensor holes
+    got = ctx.quantized_normals(depth)
+    exp = oracle.quantized_normals(depth)
+    assert np.array_equal(got, exp), int((got != exp).sum())
+    if seed <= 2:
+        assert (exp != 0).sum() > 1000
+
+
+def test_normals_far_and_thresholds(ctx, oracle):
+    depth = np.full((120, 160), 2500, np.uint16)               # beyond distance_threshold -> all zero
+    assert not ctx.quantized_normals(depth).any()
+    d2, _, _ = _scene(2, 320, 240)
+    assert np.array_equal(ctx.quantized_normals(d2, 900, 20), oracle.quantized_normals(d2, 900, 20))
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (1280, 720), (321, 241), (50, 34)])
+def test_pyrdown_bit_exact(ctx, oracle, w, h):
+    bgr = np.random.default_rng(w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    assert np.array_equal(ctx.pyrdown_bgr(bgr), oracle.pyrdown_bgr(bgr))
+
+
+@pytest.mark.parametrize("levels,T", [(2, [5, 8]), (1, [5])])
+def test_match_from_images_bit_exact(ctx, oracle, levels, T):
+    """Detector::match from BGR + depth: quantized pyramid and final match list equal the oracle's."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=levels, seed=5, n_views=4,
+                                 n_random=20)
+    det = api.Detector(ctx, 2, T)
+    det.add_class(sc["bank"])
+    det.finalize(640, 480)
+    got, n_got = det.match(sc["bgr"], sc["depth"], 70.0)
+    exp, n_exp = oracle.match_images(sc["bgr"], sc["depth"], T, [sc["bank"]], 70.0)
+    for a, b in zip(det.last_quantized(), oracle.quantize_pyramid(sc["bgr"], sc["depth"], levels)):
+        assert np.array_equal(a, b)
+    assert n_exp > 0 and n_got == n_exp
+    for k in ("x", "y", "class_idx", "template_id"):
+        assert np.array_equal(got[k], exp[k])
+    assert np.array_equal(got["similarity"].view(np.uint32), exp["similarity"].view(np.uint32))
+    det.close()

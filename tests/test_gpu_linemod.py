@@ -1,0 +1,203 @@
+"""GPU parity: the HIP LINEMOD path (through the C ABI) vs the oracle, bit-exact.
+
+Covers spread/response/linearize (linemod.cpp:950-1088), similarity + addSimilarities
+(:1130-1214, 1322-1338), matchClass incl. refinement (:1451-1577) and sort/unique (:1437-1439),
+plus the quirks of SURVEY.md section 8 (Q1 row wrap, Q2 over-read, Q3 +0.5f, Q4 -1 argmax,
+Q5 canonical order).
+"""
+import numpy as np
+import pytest
+
+from fealess_amd import api, synth
+from fealess_amd.bank import TemplateBank
+
+pytestmark = pytest.mark.gpu
+
+
+def _quant_pyramid(rng, w0, h0, levels, M, density=0.35):
+    return [synth.random_quantized(rng, w0 >> l, h0 >> l, density) for l in range(levels) for _ in range(M)]
+
+
+def _assert_matches_equal(got, exp):
+    assert len(got) == len(exp), (len(got), len(exp))
+    for k in ("x", "y", "class_idx", "template_id"):
+        assert np.array_equal(got[k], exp[k]), k
+    assert np.array_equal(got["similarity"].view(np.uint32), exp["similarity"].view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,T", [(640, 480, 5), (320, 240, 8), (320, 180, 4), (64, 48, 8), (80, 48, 16)])
+def test_linear_memories_bit_exact(ctx, oracle, w, h, T):
+    rng = np.random.default_rng(w * 7 + T)
+    q = synth.random_quantized(rng, w, h, 0.2)
+    got = ctx.build_linear_memories(q, T)
+    exp = oracle.build_linear_memories(q, T)
+    assert got.shape == exp.shape
+    assert np.array_equal(got, exp)
+
+
+def test_linear_memories_asserts(ctx):
+    q = np.zeros((45, 80), np.uint8)          # 45 % 8 != 0: CV_Assert linemod.cpp:1062
+    with pytest.raises(api.FealessError) as e:
+        ctx.build_linear_memories(q, 8)
+    assert e.value.code == -3
+
+
+@pytest.mark.parametrize("levels,T,w0,h0,n,thr", [
+    (1, [5], 640, 480, 16, 60.0),             # C1-like: single level, scan at level 0
+    (2, [5, 8], 640, 480, 120, 70.0),         # default VGA pyramid
+    (3, [5, 8, 4], 1280, 720, 40, 70.0),      # C3 geometry (M4 of SURVEY: T = {5,8,4})
+])
+def test_match_quantized_bit_exact(ctx, oracle, levels, T, w0, h0, n, thr):
+    M = 2
+    rng = np.random.default_rng(levels * 100 + n)
+    qs = _quant_pyramid(rng, w0, h0, levels, M)
+    bank = synth.make_bank("obj", n, levels, M, w0, h0, seed=n, qs=qs, planted_frac=0.25)
+    det = api.Detector(ctx, M, T)
+    det.add_class(bank)
+    det.finalize(w0, h0)
+    got, n_got = det.match_quantized(qs, thr)
+    exp, n_exp = oracle.match_quantized(qs, w0, h0, T, [bank], thr)
+    assert n_exp > 0, "test is vacuous: no matches"
+    assert n_got == n_exp
+    _assert_matches_equal(got, exp)
+    # raw u16 score maps of every pyramid (similarity + addSimilarities)
+    maps = det.similarity_maps(0, n)
+    lms = [oracle.build_linear_memories(qs[(levels - 1) * M + m], T[-1]) for m in range(M)]
+    wl, hl = w0 >> (levels - 1), h0 >> (levels - 1)
+    for g in range(0, n, max(1, n // 16)):
+        e = oracle.total_similarity(lms, bank, g, wl, hl, T[-1])
+        assert np.array_equal(maps[g], e), g
+    det.close()
+
+
+def test_match_single_modality_and_multi_class(ctx, oracle):
+    rng = np.random.default_rng(5)
+    w0, h0, T = 320, 240, [4, 8]
+    qs = _quant_pyramid(rng, w0, h0, 2, 1)
+    banks = [synth.make_bank(name, 30, 2, 1, w0, h0, seed=i + 1, qs=qs, planted_frac=0.3, bbox=96)
+             for i, name in enumerate(["zeta", "alpha", "mid"])]
+    det = api.Detector(ctx, 1, T)
+    for b in banks:
+        det.add_class(b)
+    det.finalize(w0, h0)
+    got, n_got = det.match_quantized(qs, 65.0)
+    exp, n_exp = oracle.match_quantized(qs, w0, h0, T, sorted(banks, key=lambda b: b.class_id), 65.0)
+    assert n_exp > 0 and n_got == n_exp
+    _assert_matches_equal(got, exp)
+    det.close()
+
+
+def _one_template_bank(levels, M, specs):
+    """specs: per (l, m) dict(width, height, offset_x, offset_y, features)."""
+    b = TemplateBank("obj", levels, M)
+    b.add_pyramid([dict(pyramid_level=i // M, **s) for i, s in enumerate(specs)])
+    return b
+
+
+def test_quirks_overread_oob_and_big_template(ctx, oracle):
+    """Q2: feature y == height with height % T == 0 reads past its linear-memory row; features
+    outside the image are skipped; a template larger than the search range makes max_x < border
+    (negative centre, C truncating division); all-zero patches give best_r = best_c = -1 (Q4)."""
+    rng = np.random.default_rng(11)
+    w0, h0, T = 320, 240, [5, 8]
+    qs = _quant_pyramid(rng, w0, h0, 2, 2, density=0.6)
+    feats0 = np.array([[0, 0, 1], [10, 40, 3], [35, 40, 7], [400, 3, 2], [5, 300, 2], [-3, 4, 1]], np.int32)
+    feats1 = np.array([[0, 0, 1], [5, 16, 3], [17, 16, 7], [9, 16, 0]], np.int32)   # y == height == 16, 16 % 8 == 0
+    specs = [dict(width=40, height=40, offset_x=10, offset_y=10, features=feats0),
+             dict(width=40, height=40, offset_x=10, offset_y=10, features=feats0[::-1].copy()),
+             dict(width=16, height=16, offset_x=5, offset_y=5, features=feats1),
+             dict(width=16, height=16, offset_x=5, offset_y=5, features=feats1)]
+    big0 = np.array([[0, 0, 0], [250, 200, 4], [100, 100, 2]], np.int32)
+    big1 = np.array([[0, 0, 0], [125, 100, 4], [50, 50, 2]], np.int32)
+    big = [dict(width=300, height=230, offset_x=0, offset_y=0, features=big0),
+           dict(width=300, height=230, offset_x=0, offset_y=0, features=big0),
+           dict(width=150, height=115, offset_x=0, offset_y=0, features=big1),
+           dict(width=150, height=115, offset_x=0, offset_y=0, features=big1)]
+    bank = TemplateBank("obj", 2, 2)
+    bank.add_pyramid([dict(pyramid_level=i // 2, **s) for i, s in enumerate(specs)])
+    bank.add_pyramid([dict(pyramid_level=i // 2, **s) for i, s in enumerate(big)])
+    det = api.Detector(ctx, 2, T)
+    det.add_class(bank)
+    det.finalize(w0, h0)
+    for thr in (0.0, 30.0, 55.0):
+        got, n_got = det.match_quantized(qs, thr)
+        exp, n_exp = oracle.match_quantized(qs, w0, h0, T, [bank], thr)
+        assert n_got == n_exp, thr
+        _assert_matches_equal(got, exp)
+    maps = det.similarity_maps(0, 2)
+    lms = [oracle.build_linear_memories(qs[2 + m], 8) for m in range(2)]
+    for g in range(2):
+        assert np.array_equal(maps[g], oracle.total_similarity(lms, bank, g, 160, 120, 8))
+    det.close()
+
+
+def test_empty_bank_and_no_match(ctx, oracle):
+    rng = np.random.default_rng(2)
+    qs = _quant_pyramid(rng, 320, 240, 2, 2)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(TemplateBank("obj", 2, 2))
+    det.finalize(320, 240)
+    got, n = det.match_quantized(qs, 75.0)
+    assert n == 0 and len(got) == 0
+    det.close()
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(synth.make_bank("obj", 10, 2, 2, 320, 240, seed=3, bbox=96))
+    det.finalize(320, 240)
+    got, n = det.match_quantized(qs, 99.0)
+    exp, n_exp = oracle.match_quantized(qs, 320, 240, [5, 8], det.banks, 99.0)
+    assert n == n_exp == 0
+    det.close()
+
+
+def test_candidate_overflow_is_reported(ctx):
+    rng = np.random.default_rng(4)
+    qs = _quant_pyramid(rng, 320, 240, 1, 1, density=0.9)
+    det = api.Detector(ctx, 1, [8])
+    det.add_class(synth.make_bank("obj", 40, 1, 1, 320, 240, seed=9, bbox=64))
+    det.finalize(320, 240, max_batch=1, max_candidates=64)
+    with pytest.raises(api.FealessError) as e:
+        det.match_quantized(qs, -100.0)       # raw_threshold 0: every non-zero cell is a candidate
+    assert e.value.code == -4
+    det.close()
+
+
+def test_more_than_63_features_rejected(ctx):
+    b = TemplateBank("obj", 1, 1)
+    f = np.zeros((64, 3), np.int32)
+    b.add_pyramid([dict(width=10, height=10, offset_x=0, offset_y=0, pyramid_level=0, features=f)])
+    det = api.Detector(ctx, 1, [8])
+    with pytest.raises(api.FealessError) as e:
+        det.add_class(b)                      # CV_Assert(features.size() <= 63), linemod.cpp:1137
+    assert e.value.code == -3
+    det.close()
+
+
+def test_match_property_full_size(ctx):
+    """At BASELINE sizes (2000 templates): planted templates must be found at their planted
+    position with similarity 100, and the list must be sorted and duplicate-free."""
+    rng = np.random.default_rng(77)
+    w0, h0, T = 640, 480, [5, 8]
+    qs = _quant_pyramid(rng, w0, h0, 2, 2, density=0.3)
+    bank = synth.make_bank("obj", 2000, 2, 2, w0, h0, seed=12, qs=qs, planted_frac=0.01)
+    det = api.Detector(ctx, 2, T)
+    det.add_class(bank)
+    det.finalize(w0, h0)
+    got, n = det.match_quantized(qs, 90.0)
+    assert n > 0
+    sim = got["similarity"]
+    assert np.all(sim[:-1] >= sim[1:])
+    key = np.stack([got["x"], got["y"], sim.view(np.int32)], 1)
+    assert not np.any(np.all(key[1:] == key[:-1], axis=1))
+    t, f, p = bank.arrays()
+    best = {}
+    for m in got:
+        best.setdefault(int(m["template_id"]), m)
+    hits = 0
+    for tid, m in best.items():
+        hdr = t[tid * 4]
+        if m["similarity"] == 100.0:
+            hits += 1
+            # spread is anchored top-left over T x T: a perfect score needs x in (ox - T, ox]
+            assert abs(int(m["x"]) - int(hdr["offset_x"])) <= 5 and abs(int(m["y"]) - int(hdr["offset_y"])) <= 5
+    assert hits >= 10
+    det.close()
