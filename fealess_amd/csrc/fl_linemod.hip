@@ -366,8 +366,6 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
 {
   fl_context *ctx = det->ctx;
   const int L = det->L, M = det->M;
-  // zero the per-frame counters
-  FL_HIP(ctx, hipMemset2DAsync(det->d_ws + det->off_count, det->ws_stride, 0, 16, n_frames, ctx->stream));
   {
     const FlLevelGeom &g = det->geom[L - 1];
     ScanArgs a;
@@ -442,6 +440,8 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
 int fl_launch_match_core(fl_detector *det, int n_frames, float threshold)
 {
   fl_context *ctx = det->ctx;
+  // zero the per-frame counters
+  FL_HIP(ctx, hipMemset2DAsync(det->d_ws + det->off_count, det->ws_stride, 0, 16, n_frames, ctx->stream));
   for (int l = 0; l < det->L; ++l) {
     const FlLevelGeom &g = det->geom[l];
     for (int m = 0; m < det->M; ++m) {
@@ -531,6 +531,7 @@ extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16
   // re-run the scan on frame 0's resident linear memories with the debug tap on; threshold 200%
   // keeps the candidate buffer untouched in practice (counters are reset by the launcher)
   det->have_times = false;
+  FL_HIP(ctx, hipMemsetAsync(det->d_ws + det->off_count, 0, 16, ctx->stream));
   rc = launch_scan_refine_sort(det, 1, 200.0f, (uint16_t *)d, first, count);
   if (rc) return rc;
   FL_HIP(ctx, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -42,15 +42,15 @@ def test_linear_memories_asserts(ctx):
     assert e.value.code == -3
 
 
-@pytest.mark.parametrize("levels,T,w0,h0,n,thr", [
-    (1, [5], 640, 480, 16, 60.0),             # C1-like: single level, scan at level 0
-    (2, [5, 8], 640, 480, 120, 70.0),         # default VGA pyramid
-    (3, [5, 8, 4], 1280, 720, 40, 70.0),      # C3 geometry (M4 of SURVEY: T = {5,8,4})
+@pytest.mark.parametrize("levels,T,w0,h0,n,thr,density", [
+    (1, [5], 640, 480, 16, 80.0, 0.06),       # C1-like: single level, scan at level 0
+    (2, [5, 8], 640, 480, 120, 70.0, 0.03),   # default VGA pyramid
+    (3, [5, 8, 4], 1280, 720, 40, 70.0, 0.03),  # C3 geometry (M4 of SURVEY: T = {5,8,4})
 ])
-def test_match_quantized_bit_exact(ctx, oracle, levels, T, w0, h0, n, thr):
+def test_match_quantized_bit_exact(ctx, oracle, levels, T, w0, h0, n, thr, density):
     M = 2
     rng = np.random.default_rng(levels * 100 + n)
-    qs = _quant_pyramid(rng, w0, h0, levels, M)
+    qs = _quant_pyramid(rng, w0, h0, levels, M, density)
     bank = synth.make_bank("obj", n, levels, M, w0, h0, seed=n, qs=qs, planted_frac=0.25)
     det = api.Detector(ctx, M, T)
     det.add_class(bank)
@@ -177,7 +177,7 @@ def test_match_property_full_size(ctx):
     position with similarity 100, and the list must be sorted and duplicate-free."""
     rng = np.random.default_rng(77)
     w0, h0, T = 640, 480, [5, 8]
-    qs = _quant_pyramid(rng, w0, h0, 2, 2, density=0.3)
+    qs = _quant_pyramid(rng, w0, h0, 2, 2, density=0.03)
     bank = synth.make_bank("obj", 2000, 2, 2, w0, h0, seed=12, qs=qs, planted_frac=0.01)
     det = api.Detector(ctx, 2, T)
     det.add_class(bank)
