@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--templates", type=int, default=360)
     ap.add_argument("--levels", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
     ap.add_argument("--icp-iters", type=int, default=20)
     ap.add_argument("--icp-mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
@@ -138,7 +138,7 @@ def main():
     bank, bgrs, depths, scenes = build_workload(ctx, args, rank)
     det = api.Detector(ctx, 2, T)
     det.add_class(bank)
-    det.finalize(640, 480, max_batch=args.batch)
+    det.finalize(640, 480, max_batch=args.batch, max_candidates=4096)
     B = args.batch
     d_bgr = torch.from_numpy(bgrs).cuda()
     d_depth = torch.from_numpy(depths.view(np.int16)).cuda()

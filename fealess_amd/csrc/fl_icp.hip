@@ -27,10 +27,16 @@
 #include <math.h>
 #include <string.h>
 
-#define ICP_MAX_THREADS 1024
+#define ICP_BS 256               // threads per frame workgroup = rows per LDS tile
+#define ICP_MAX_THREADS ICP_BS
 
+// HBM layout of one frame's ICP workspace (n = capacity in points):
+//   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
+//   mod   n x 3 f32   model cloud, transformed in place every iteration
+//   sref  n x float4  reference cloud sorted by grid cell, w = original index (bit pattern)
+//   cell_start / cell_cur   CSR offsets of the x/y cell grid
 struct IcpWsLayout {
-  size_t ref, mod, sref, sidx, prod, dterm, cell_start, cell_cur, total;
+  size_t ref, mod, sref, cell_start, cell_cur, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -41,10 +47,7 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.ncell_max = n + 4096;
   L.ref = o; o = al256(o + 12 * nn);
   L.mod = o; o = al256(o + 12 * nn);
-  L.sref = o; o = al256(o + 12 * nn);
-  L.sidx = o; o = al256(o + 4 * nn);
-  L.prod = o; o = al256(o + 64 * nn);
-  L.dterm = o; o = al256(o + 4 * nn);
+  L.sref = o; o = al256(o + 16 * nn);
   L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
   L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
   L.total = o;
@@ -91,13 +94,16 @@ struct IcpShared {
   float xmin, ymin, inv_c;
   int GX, GY;
   float sums[16];
-  double dsum[16][16];   // [wave][scalar]
-  int iscan[ICP_MAX_THREADS / 64 + 1];
+  double dsum[ICP_BS / 64][16];   // [wave][scalar]
+  int iscan[ICP_BS / 64 + 1];
   int ibase;
-  int ired[4][16];
-  float fred[4][16];
-  float t_init[3];
+  float fred[4][ICP_BS / 64];
   int n, rect_m[4], rect_r[4], status, g;
+  // double-buffered LDS tiles feeding the sequential float32 chains (FL_ICP_PARITY):
+  // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords, pad) of row r of tile b;
+  // +1 column of padding puts the 16 chain lanes on 16 different banks
+  float prod[2][16][ICP_BS + 1];
+  float dtile[2][ICP_BS];
 };
 
 __device__ __forceinline__ bool vvalid(float z) { return z <= 900.0f; }      // common.cpp:261-266
@@ -303,6 +309,21 @@ __device__ __forceinline__ float chain_sum(const float *tab, int n, int stride, 
   return acc;
 }
 
+// one chain step over an LDS tile: acc += col[0], col[1], ... col[rows-1], strictly in order
+__device__ __forceinline__ float chain_tile(const float *col, int rows, float acc)
+{
+  int r = 0;
+  for (; r + 16 <= rows; r += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = col[r + u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  for (; r < rows; ++r) acc += col[r];
+  return acc;
+}
+
 // ---- uniform x/y grid over the reference cloud --------------------------------------------------
 __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
 {
@@ -311,8 +332,8 @@ __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
   return c;
 }
 
-__device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float *sref, int *sidx, int *cell_start,
-                           int *cell_cur, int ncell_max)
+__device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sref, int *cell_start, int *cell_cur,
+                           int ncell_max)
 {
   // bounding box of the finite points
   float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
@@ -395,18 +416,16 @@ __device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float *sre
     const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
       const int slot = atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
-      sref[3 * slot] = x;
-      sref[3 * slot + 1] = y;
-      sref[3 * slot + 2] = z;
-      sidx[slot] = i;
+      sref[slot] = make_float4(x, y, z, __int_as_float(i));
     }
   }
   __syncthreads();
 }
 
 // exact 1-NN within squared distance thr (float compare as the reference's `dists <= dist_thr`)
-__device__ __forceinline__ void nn_query(const IcpShared &S, const float *sref, const int *sidx, const int *cell_start,
-                                         float qx, float qy, float qz, float thr, int *bi, float *bd)
+__device__ __forceinline__ void nn_query(const IcpShared &S, const float4 *__restrict__ sref,
+                                         const int *__restrict__ cell_start, float qx, float qy, float qz, float thr,
+                                         int *bi, float *bd)
 {
   int best_i = -1;
   float best_d = INFINITY;
@@ -420,15 +439,34 @@ __device__ __forceinline__ void nn_query(const IcpShared &S, const float *sref, 
       cy0 = cell_of(qy - r, S.ymin, S.inv_c, S.GY);
       cy1 = cell_of(qy + r, S.ymin, S.inv_c, S.GY);
     }
-    for (int cy = cy0; cy <= cy1; ++cy) {
-      const int b = cell_start[cy * S.GX + cx0], e = cell_start[cy * S.GX + cx1 + 1];   // cells of a row are contiguous
-      for (int s = b; s < e; ++s) {
-        const float dx = qx - sref[3 * s], dy = qy - sref[3 * s + 1], dz = qz - sref[3 * s + 2];
-        float d = dx * dx;                              // cvflann::L2_Simple<float>
-        d += dy * dy;
-        d += dz * dz;
-        const int j = sidx[s];
-        if (d < best_d || (d == best_d && j < best_i)) { best_d = d; best_i = j; }
+    // Loads are issued in batches (4 row headers, then 8 candidates) before anything is consumed:
+    // the search is latency-bound, and clamped duplicate candidates cannot change the result.
+    for (int cy = cy0; cy <= cy1; cy += 4) {
+      int rb[4], re[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cyu = min(cy + u, cy1);
+        rb[u] = cell_start[cyu * S.GX + cx0];           // cells of a row are contiguous
+        re[u] = cell_start[cyu * S.GX + cx1 + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (cy + u > cy1) break;
+        const int b = rb[u], e = re[u];
+        for (int s = b; s < e; s += 8) {
+          float4 p[8];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) p[v] = sref[min(s + v, e - 1)];
+#pragma unroll
+          for (int v = 0; v < 8; ++v) {
+            const float dx = qx - p[v].x, dy = qy - p[v].y, dz = qz - p[v].z;
+            float d = dx * dx;                          // cvflann::L2_Simple<float>
+            d += dy * dy;
+            d += dz * dz;
+            const int j = __float_as_int(p[v].w);
+            if (d < best_d || (d == best_d && j < best_i)) { best_d = d; best_i = j; }
+          }
+        }
       }
     }
   }
@@ -436,42 +474,51 @@ __device__ __forceinline__ void nn_query(const IcpShared &S, const float *sref, 
   *bd = best_i >= 0 ? best_d : NAN;
 }
 
-// ---- getL2distClouds (ICP.cpp:68-111) over the index-paired clouds ------------------------------
-__device__ void l2dist_phase(IcpShared &S, const float *mod, const float *ref, float *dterm, int n, float thr, int mode,
-                             const float *Ropt, const float *Topt, float *mod_w)
+// ---- getL2distClouds (ICP.cpp:68-111) over the index-paired clouds, optionally fused with the
+// in-place transformPoints that precedes it (ICP.cpp:28-45, 756).  FL_ICP_PARITY: the per-point
+// terms go through double-buffered LDS tiles and one lane adds them in index order (the
+// reference's `dist_mean += dist` chain) while the other waves already compute the next tile.
+__device__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, float thr, int mode, const float *Ropt,
+                             const float *Topt)
 {
   int counter = 0, inl = 0;
   double dsum[1] = {0.0};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float a[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]};
-    if (Ropt && vvalid(a[2])) {                           // transformPoints in place (:28-45, :756)
-      float o[3];
-      mat_vec(Ropt, a, o);
-      a[0] = o[0] + Topt[0];
-      a[1] = o[1] + Topt[1];
-      a[2] = o[2] + Topt[2];
-      mod_w[3 * i] = a[0];
-      mod_w[3 * i + 1] = a[1];
-      mod_w[3 * i + 2] = a[2];
-    }
-    const float b0 = ref[3 * i], b1 = ref[3 * i + 1], b2 = ref[3 * i + 2];
+  float acc = 0.0f;
+  const int ntiles = (n + ICP_BS - 1) / ICP_BS;
+  for (int t = 0; t < ntiles; ++t) {
+    const int i = t * ICP_BS + threadIdx.x;
     float term = 0.0f;
-    if (vvalid(b2) && vvalid(a[2])) {
-      const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
-      // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
-      const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
-      if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
-      ++counter;
+    if (i < n) {
+      float a[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]};
+      if (Ropt && vvalid(a[2])) {                         // transformPoints in place (:28-45, :756)
+        float o[3];
+        mat_vec(Ropt, a, o);
+        a[0] = o[0] + Topt[0];
+        a[1] = o[1] + Topt[1];
+        a[2] = o[2] + Topt[2];
+        mod[3 * i] = a[0];
+        mod[3 * i + 1] = a[1];
+        mod[3 * i + 2] = a[2];
+      }
+      const float b0 = ref[3 * i], b1 = ref[3 * i + 1], b2 = ref[3 * i + 2];
+      if (vvalid(b2) && vvalid(a[2])) {
+        const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
+        // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
+        const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+        if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
+        ++counter;
+      }
     }
-    dterm[i] = term;
+    if (mode == FL_ICP_PARITY) {
+      S.dtile[t & 1][threadIdx.x] = term;                // non-inliers add an exact +0.0f
+      __syncthreads();
+      if (threadIdx.x == 0) acc = chain_tile(S.dtile[t & 1], min(ICP_BS, n - t * ICP_BS), acc);
+    }
   }
   counter = block_sum_int(S, counter);
   inl = block_sum_int(S, inl);
   float dm;
   if (mode == FL_ICP_PARITY) {
-    __syncthreads();                                     // dterm visible to wave 0
-    float acc = 0.f;
-    if (threadIdx.x < 64) acc = chain_sum(dterm, n, 1, 0, threadIdx.x == 0);
     if (threadIdx.x == 0) S.sums[0] = acc;
     __syncthreads();
     dm = S.sums[0];
@@ -496,9 +543,9 @@ __device__ void l2dist_phase(IcpShared &S, const float *mod, const float *ref, f
 __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model, int it_thr, float dmt,
                         float ddt, int mode, fl_icp_result *res)
 {
-  float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod), *sref = (float *)(wsb + L.sref);
-  int *sidx = (int *)(wsb + L.sidx), *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
-  float *prod = (float *)(wsb + L.prod), *dterm = (float *)(wsb + L.dterm);
+  float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
+  float4 *sref = (float4 *)(wsb + L.sref);
+  int *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
 
   if (threadIdx.x == 0) {
     for (int i = 0; i < 9; ++i) S.R[i] = 0.f;           // cv::Matx33f R; cv::Vec3f T; zero-initialised
@@ -520,7 +567,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     __syncthreads();
     return;
   }
-  build_grid(S, ref, n_ref, sref, sidx, cell_start, cell_cur, L.ncell_max);
+  build_grid(S, ref, n_ref, sref, cell_start, cell_cur, L.ncell_max);
   // copyPoints(pts_model, pts_model_tmp) (:666-667): invalid points become Vec3f() = 0
   for (int i = threadIdx.x; i < n_model; i += blockDim.x)
     if (!vvalid(mod[3 * i + 2])) { mod[3 * i] = 0.f; mod[3 * i + 1] = 0.f; mod[3 * i + 2] = 0.f; }
@@ -529,7 +576,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     S.dist_diff = FLT_MAX;
   }
   __syncthreads();
-  l2dist_phase(S, mod, ref, dterm, n_model, FLT_MAX, mode, nullptr, nullptr, nullptr);   // :670
+  l2dist_phase(S, mod, ref, n_model, FLT_MAX, mode, nullptr, nullptr);                  // :670
 
   for (;;) {
     if (threadIdx.x == 0) S.go = (S.dist_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);   // :684
@@ -540,46 +587,50 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     const int iter = S.iter;
     const float thr = S.thr;
     const int rows = iter == 1 ? n_ref : n_model;
+    const int ntiles = (rows + ICP_BS - 1) / ICP_BS;
     int kept = 0;
     double ds[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) ds[k] = 0.0;
-    for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+    float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
+    for (int t = 0; t < ntiles; ++t) {
+      const int i = t * ICP_BS + threadIdx.x;
       float m[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
       bool have_m = false, have_pair = false;
-      if (iter == 1) {                                   // :700-704: index pairs, invalid -> 0
-        if (i < n_model) {
-          have_m = true;
-          have_pair = true;
-          if (vvalid(mod[3 * i + 2])) { m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2]; }
-        }
-        if (vvalid(ref[3 * i + 2])) { r[0] = ref[3 * i]; r[1] = ref[3 * i + 1]; r[2] = ref[3 * i + 2]; }
-      } else {                                           // PointsCorresponding :193-279
-        int j;
-        float d;
-        const float qx = mod[3 * i], qy = mod[3 * i + 1], qz = mod[3 * i + 2];
-        nn_query(S, sref, sidx, cell_start, qx, qy, qz, thr, &j, &d);
-        if (d <= thr) {
-          have_m = have_pair = true;
-          m[0] = qx; m[1] = qy; m[2] = qz;
-          r[0] = ref[3 * j]; r[1] = ref[3 * j + 1]; r[2] = ref[3 * j + 2];
-          ++kept;
+      if (i < rows) {
+        if (iter == 1) {                                 // :700-704: index pairs, invalid -> 0
+          if (i < n_model) {
+            have_m = true;
+            have_pair = true;
+            if (vvalid(mod[3 * i + 2])) { m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2]; }
+          }
+          if (vvalid(ref[3 * i + 2])) { r[0] = ref[3 * i]; r[1] = ref[3 * i + 1]; r[2] = ref[3 * i + 2]; }
+        } else {                                         // PointsCorresponding :193-279
+          int j;
+          float d;
+          const float qx = mod[3 * i], qy = mod[3 * i + 1], qz = mod[3 * i + 2];
+          nn_query(S, sref, cell_start, qx, qy, qz, thr, &j, &d);
+          if (d <= thr) {
+            have_m = have_pair = true;
+            m[0] = qx; m[1] = qy; m[2] = qz;
+            r[0] = ref[3 * j]; r[1] = ref[3 * j + 1]; r[2] = ref[3 * j + 2];
+            ++kept;
+          }
         }
       }
-      float row[16];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) row[a * 3 + b] = have_pair ? m[a] * r[b] : 0.0f;   // (*it_s) * (*it_ref).t()
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { row[9 + k] = have_m ? m[k] : 0.0f; row[12 + k] = r[k]; }
-      row[15] = 0.0f;
       if (mode == FL_ICP_PARITY) {
-        float4 *dst = (float4 *)(prod + (size_t)i * 16);
-        dst[0] = make_float4(row[0], row[1], row[2], row[3]);
-        dst[1] = make_float4(row[4], row[5], row[6], row[7]);
-        dst[2] = make_float4(row[8], row[9], row[10], row[11]);
-        dst[3] = make_float4(row[12], row[13], row[14], row[15]);
+        // dropped pairs contribute an exact +0.0f, so the chains below are branch-free
+        float (*tile)[ICP_BS + 1] = S.prod[t & 1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) tile[a * 3 + b][threadIdx.x] = have_pair ? m[a] * r[b] : 0.0f;   // (*it_s) * (*it_ref).t()
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { tile[9 + k][threadIdx.x] = have_m ? m[k] : 0.0f; tile[12 + k][threadIdx.x] = r[k]; }
+        __syncthreads();
+        // wave 0, lane k: scalar k of getMean (:8-25) / the covariance loop (:731-735), in row order;
+        // waves 1-3 run ahead into the other buffer meanwhile
+        if (threadIdx.x < 15) acc = chain_tile(tile[threadIdx.x], min(ICP_BS, rows - t * ICP_BS), acc);
       } else {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -599,11 +650,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
       continue;
     }
     if (mode == FL_ICP_PARITY) {
-      __syncthreads();
-      if (threadIdx.x < 64) {
-        const float acc = chain_sum(prod, rows, 16, threadIdx.x & 15, threadIdx.x < 15);
-        if (threadIdx.x < 15) S.sums[threadIdx.x] = acc;
-      }
+      if (threadIdx.x < 15) S.sums[threadIdx.x] = acc;
       __syncthreads();
     } else {
       block_sum_double<15>(S, ds);
@@ -637,7 +684,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     for (int k = 0; k < 3; ++k) To[k] = S.Topt[k];
     const float old_mean = S.dist_mean;
     __syncthreads();
-    l2dist_phase(S, mod, ref, dterm, n_model, 3 * old_mean, mode, Ro, To, mod);   // :756, :778-780
+    l2dist_phase(S, mod, ref, n_model, 3 * old_mean, mode, Ro, To);                // :756, :778-780
     if (threadIdx.x == 0) {
       S.dist_diff = old_mean - S.dist_mean;
       float RT[3];                                       // :793-797
@@ -877,7 +924,7 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
   return FL_OK;
 }
 
-static int icp_threads(int n_frames) { return n_frames >= 192 ? 256 : (n_frames >= 48 ? 512 : 1024); }
+static int icp_threads(int) { return ICP_BS; }
 
 extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model, int icp_it_thr,
                       float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem, fl_icp_result *res)
@@ -907,7 +954,7 @@ extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float 
   a.job.n_ref = n_ref;
   a.job.n_model = n_model;
   a.results = dres;
-  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(1024), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(ICP_BS), 0, ctx->stream, a);
   FL_HIP(ctx, hipGetLastError());
   fl_recognition_result *h = nullptr;
   rc = fl_pinned(ctx, sizeof(*h), (void **)&h);
@@ -967,7 +1014,7 @@ extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const 
   a.job.model_depth = dm;
   a.job.scene_depth = dsn;
   a.results = dres;
-  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(1024), 0, ctx->stream, a);
+  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(ICP_BS), 0, ctx->stream, a);
   FL_HIP(ctx, hipGetLastError());
   fl_recognition_result *hres = nullptr;
   rc = fl_pinned(ctx, sizeof(*hres), (void **)&hres);
