@@ -1,0 +1,159 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/fealess_hip.h declares, fails loudly without a GPU (no CPU fallback), and the host-only
+entry points (fl_lm_label_stride, fl_merge_topk) behave.  Also the CadReco adapter's bank I/O
+(OpenCV FileStorage YAML subset + 16-bit PNG), which needs no GPU."""
+import ctypes as C
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from fealess_amd import _lib as L
+from fealess_amd.bank import MATCH_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_header_symbols_all_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "fealess_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fl_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = L.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in fealess_hip.h but not exported"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    assert lib.fl_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    if _has_gpu():
+        pytest.skip("a GPU is present")
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.fl_context_create(0, C.byref(h)) == L.FL_ERR_NO_DEVICE and not h.value
+    from fealess_amd import api
+    with pytest.raises(api.FealessError):
+        api.Context(0)
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must never import, link or load anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "fealess_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "liboracle" not in txt and "oracle_py" not in txt and "fealess_oracle.h" not in txt, (dirpath, f)
+
+
+def test_lm_label_stride_matches_oracle(oracle):
+    lib = L.load()
+    for (w, h, T) in [(640, 480, 5), (320, 240, 8), (1280, 720, 5), (320, 180, 4), (64, 48, 8)]:
+        assert lib.fl_lm_label_stride(w, h, T) == oracle.lib().orc_lm_label_stride(w, h, T)
+
+
+def test_merge_topk_equals_global_sort_unique(oracle):
+    rng = np.random.default_rng(0)
+    n = 400
+    rec = np.zeros(n, MATCH_DTYPE)
+    rec["x"] = rng.integers(0, 8, n) * 5
+    rec["y"] = rng.integers(0, 6, n) * 5
+    rec["similarity"] = rng.integers(160, 200, n) / np.float32(2.0)
+    rec["template_id"] = rng.integers(0, 50, n)
+    rec["template_id"][::17] = -1            # padding records of short shards
+    from fealess_amd.api import merge_topk
+    got = merge_topk(rec, n)
+    live = rec[rec["template_id"] >= 0].copy()
+    live = np.ascontiguousarray(live)
+    k = oracle.lib().orc_sort_unique(live.ctypes.data_as(C.c_void_p), len(live))
+    assert len(got) == k and got.tobytes() == live[:k].tobytes()
+
+
+# ---- CadReco adapter bank I/O --------------------------------------------------------------------
+def _cad():
+    path = os.path.join(ROOT, "fealess_amd", "cadreco", "libcadreco_hip.so")
+    lib = C.CDLL(path)
+    lib.cadreco_version.restype = C.c_char_p
+    return lib
+
+
+def write_png16(path, img):
+    img = np.ascontiguousarray(img, dtype=">u2")
+    h, w = img.shape
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def write_linemod_yaml(path, bank, T, modalities=("ColorGradient", "DepthNormal")):
+    """OpenCV FileStorage YAML 1.0 as cup_linemod's writeLinemod lays it out (linemod_if.cpp:49-63)."""
+    t, f, p = bank.arrays()
+    LM = bank.levels * bank.modalities
+    o = ["%YAML:1.0", "---", f"pyramid_levels: {bank.levels}", "T: [ " + ", ".join(str(v) for v in T) + " ]", "modalities:"]
+    for m in modalities[:bank.modalities]:
+        if m == "ColorGradient":
+            o += ["   -", "      type: ColorGradient", "      weak_threshold: 10.", "      num_features: 63", "      strong_threshold: 55."]
+        else:
+            o += ["   -", "      type: DepthNormal", "      distance_threshold: 2000", "      difference_threshold: 50",
+                  "      num_features: 63", "      extract_threshold: 2"]
+    o += ["classes:", "   -", f'      class_id: "{bank.class_id}"',
+          "      modalities: [ " + ", ".join(modalities[:bank.modalities]) + " ]", f"      pyramid_levels: {bank.levels}",
+          "      template_pyramids:"]
+    for i in range(bank.n_pyramids):
+        pose = [repr(float(v)).rstrip("0") if "." in repr(float(v)) else repr(float(v)) for v in p[i]]
+        o += ["         -", f"            template_id: {i}",
+              "            template_pose: [ " + ", ".join(pose[:7]) + ",", "               " + ", ".join(pose[7:]) + " ]",
+              "            templates:"]
+        for k in range(LM):
+            hdr = t[i * LM + k]
+            o += ["               -", f"                  width: {hdr['width']}", f"                  height: {hdr['height']}",
+                  f"                  offset_x: {hdr['offset_x']}", f"                  offset_y: {hdr['offset_y']}",
+                  f"                  pyramid_level: {hdr['pyramid_level']}", "                  features:"]
+            for fr in f[hdr["feat_begin"]:hdr["feat_begin"] + hdr["feat_count"]]:
+                o.append(f"                     - [ {fr['x']}, {fr['y']}, {fr['label']} ]")
+    with open(path, "w") as fh:
+        fh.write("\n".join(o) + "\n")
+
+
+def test_png16_reader(tmp_path):
+    lib = _cad()
+    img = np.random.default_rng(1).integers(0, 65536, (37, 53)).astype(np.uint16)
+    p = str(tmp_path / "d.png")
+    write_png16(p, img)
+    out = np.zeros(img.size, np.uint16)
+    w, h = C.c_int(0), C.c_int(0)
+    assert lib.cadreco_read_png16(p.encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(w), C.byref(h)) == 0
+    assert (w.value, h.value) == (53, 37) and np.array_equal(out.reshape(37, 53), img)
+    assert lib.cadreco_read_png16(str(tmp_path / "missing.png").encode(), out.ctypes.data_as(C.c_void_p), out.size,
+                                  C.byref(w), C.byref(h)) == -1
+
+
+def test_linemod_yaml_reader(tmp_path):
+    from fealess_amd import synth
+    lib = _cad()
+    bank = synth.make_bank("c919-jig", 7, 2, 2, 640, 480, seed=3)
+    p = str(tmp_path / "linemod_templates.yml")
+    write_linemod_yaml(p, bank, [5, 8])
+    lv, nc, nt, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert lib.cadreco_read_linemod(p.encode(), C.byref(lv), C.byref(nc), C.byref(nt), C.byref(nf)) == 0
+    assert (lv.value, nc.value, nt.value, nf.value) == (2, 1, 7, 7 * 2 * (63 + 31))
+    assert b"HIP" in lib.cadreco_version()
+
+
+def test_cadreco_factory_rejects_unsupported_types():
+    lib = _cad()
+    lib.cadreco_create.restype = C.c_void_p
+    for unsupported in (0, 2, 3):            # EObjReco_FEATURE, BB8, PoseNet -> nullptr (obj_reco_temp.cpp:13-30)
+        assert not lib.cadreco_create(unsupported)

@@ -1,0 +1,130 @@
+"""GPU: the HIP path vs the committed golden fixtures (data only -- nothing here needs
+/root/reference), the C++ CadReco facade end to end on a data directory written in the
+reference's on-disk format, and the template-sharded top-k export/merge on one GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import util
+from fealess_amd import api, synth
+from fealess_amd import _lib as L
+from fealess_amd.bank import MATCH_DTYPE
+from test_abi_cpu import write_linemod_yaml, write_png16
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_golden_linemod(ctx):
+    g = util.golden("linemod_320x160.npz")
+    bank = util.bank_from_arrays(g["templates"], g["features"], g["poses"], 2, 2)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(bank)
+    det.finalize(320, 160)
+    m, n = det.match_quantized([g["q0"], g["q1"], g["q2"], g["q3"]], float(g["threshold"]))
+    assert n == int(g["n_matches"]) and m.tobytes() == g["matches"].tobytes()
+    assert np.array_equal(det.similarity_maps(0, bank.n_pyramids), g["sims"])
+    lm0 = ctx.build_linear_memories(g["q0"], 5)
+    crc = [int(lm0.astype(np.uint64).sum()),
+           int((lm0.astype(np.uint64) * (np.arange(lm0.size, dtype=np.uint64).reshape(lm0.shape) % 251)).sum())]
+    assert crc == g["lm_level0_mod0_crc"].tolist()
+    det.close()
+
+
+def test_golden_frontend(ctx):
+    g = util.golden("frontend_256x192.npz")
+    assert np.array_equal(ctx.quantized_orientations(g["bgr"], 10.0), g["qo"])
+    assert np.array_equal(ctx.quantized_normals(g["depth"]), g["qn"])
+    assert np.array_equal(ctx.pyrdown_bgr(g["bgr"]), g["pyrdown"])
+    assert np.array_equal(ctx.quantized_orientations(g["pyrdown"], 10.0), g["qo1"])
+
+
+def test_golden_icp(ctx):
+    g = util.golden("icp_1500.npz")
+    r = ctx.icp_cloud_to_cloud_ex(g["ref"], g["model"], 12, 0.0, -3.0e38, L.FL_ICP_PARITY)
+    assert np.array_equal(r["R"], g["R32"]) and np.array_equal(r["T"], g["T32"]) and r["dist_mean"] == g["dm32"]
+    r = ctx.icp_cloud_to_cloud_ex(g["ref"], g["model"], 12, 0.0, -3.0e38, L.FL_ICP_FAST)
+    assert np.abs(r["R"] - g["R64"]).max() <= 1e-4 and np.abs(r["T"] - g["T64"]).max() <= 1e-3
+    r = ctx.icp_cloud_to_cloud_ex(g["ref"], g["model"], 10, 0.5, 0.01, L.FL_ICP_PARITY)
+    assert r["iters"] == int(g["iters_def"]) and np.array_equal(r["R"], g["Rdef"]) and np.array_equal(r["T"], g["Tdef"])
+
+
+def test_golden_recognition(ctx):
+    g = util.golden("recognition_vga.npz")
+    bank = util.bank_from_arrays(g["templates"], g["features"], g["poses"], 2, 2, model_depths=g["model_depths"])
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(bank)
+    det.finalize(640, 480)
+    K = tuple(float(v) for v in g["K"])
+    r = det.recognize_batch([g["bgr"]], [g["depth"]], K, 75.0, 10, 0.5, 0.01)[0]
+    assert r["found"] == 1 and r["n_matches"] == int(g["n_matches"])
+    assert [r["best"]["x"], r["best"]["y"], r["best"]["template_id"]] == g["best"].tolist()
+    assert r["best"]["similarity"] == g["best_sim"] and r["det"]["n_points"] == int(g["n_points"])
+    assert np.abs(r["pose"] - g["pose"]).max() <= 1e-4 and np.array_equal(r["pose"], g["pose"])
+    r20 = det.recognize_batch([g["bgr"]], [g["depth"]], K, 75.0, 20, -1.0, -3.0e38)[0]
+    assert r20["det"]["icp"]["iters"] == 20 and np.array_equal(r20["pose"], g["pose20"])
+    det.close()
+
+
+def test_cadreco_facade_end_to_end(tmp_path, oracle):
+    """CObjRecoCAD::Create -> AddObj(dir) -> Recognition on a directory in the reference's format
+    (linemod_templates.yml + depth/<id>.png, obj_reco_lmicp.cpp:67-74,156-157)."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=13, n_views=3)
+    d = tmp_path / "obj"
+    (d / "depth").mkdir(parents=True)
+    write_linemod_yaml(str(d / "linemod_templates.yml"), sc["bank"], [5, 8])
+    for i, md in enumerate(sc["bank"].model_depths):
+        write_png16(str(d / "depth" / f"{i}.png"), md)
+    lib = C.CDLL(os.path.join(ROOT, "fealess_amd", "cadreco", "libcadreco_hip.so"))
+    lib.cadreco_create.restype = C.c_void_p
+    h = C.c_void_p(lib.cadreco_create(1))                   # EObjReco_LmICP
+    assert h.value
+    assert lib.cadreco_add_obj(h, str(tmp_path / "nope").encode()) == C.c_int(0x80000002).value   # ERROR_OPEN_FILE_FAILED
+    assert lib.cadreco_add_obj(h, str(d).encode()) == 0
+    bgr, depth = np.ascontiguousarray(sc["bgr"]), np.ascontiguousarray(sc["depth"])
+    pose = np.zeros(16, np.float32)
+    tag = C.create_string_buffer(64)
+    n = C.c_int(-1)
+    fx, fy, cx, cy = sc["K"]
+
+    def reco(kw=640, kh=480, ts=1.0):
+        return lib.cadreco_recognition(h, bgr.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p), 640, 480,
+                                       C.c_double(ts), kw, kh, C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy),
+                                       C.byref(n), pose.ctypes.data_as(C.c_void_p), tag, 64)
+    assert reco() == 0 and n.value == 1 and tag.value == b"obj"
+    exp = oracle.recognition(bgr, depth, sc["K"], [5, 8], sc["bank"], 75.0, 10, 0.5, 0.01)   # constructor defaults :52-55
+    assert np.abs(pose.reshape(4, 4) - exp["pose"]).max() <= 1e-4
+    assert pose.reshape(4, 4)[3].tolist() == [0, 0, 0, 1]
+    assert reco(kw=320) == C.c_int(0x80000001).value         # size != intrinsics size -> ERROR_INVALID_PARAM (:223-227)
+    assert reco(ts=-1.0) == C.c_int(0x80000001).value        # negative timestamp (CheckTImage :35)
+    lib.cadreco_destroy(h)
+
+
+def test_template_sharded_topk_on_one_gpu(ctx, oracle):
+    """Two 'ranks' = two detectors holding the two halves of a bank; export_topk + merge must equal
+    the single-detector match over the whole bank (C4 of BASELINE.json, minus the wire)."""
+    import torch
+    from fealess_amd import distributed as D
+    rng = np.random.default_rng(31)
+    w0, h0, T = 640, 480, [5, 8]
+    qs = [synth.random_quantized(rng, w0 >> l, h0 >> l, 0.03) for l in range(2) for _ in range(2)]
+    bank = synth.make_bank("obj", 60, 2, 2, w0, h0, seed=4, qs=qs, planted_frac=0.3)
+    k = 32
+    bufs = []
+    for rank in range(2):
+        shard, first = D.shard_bank(bank, 2, rank)
+        det = api.Detector(ctx, 2, T)
+        det.add_class(shard)
+        det.finalize(w0, h0)
+        det.match_quantized(qs, 70.0)
+        buf = torch.empty(k * MATCH_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+        det.export_topk(0, k, first, buf.data_ptr())
+        ctx.synchronize()
+        bufs.append(buf.cpu().numpy().view(MATCH_DTYPE).copy())
+        det.close()
+    merged = api.merge_topk(np.concatenate(bufs), k)
+    full, n_full = oracle.match_quantized(qs, w0, h0, T, [bank], 70.0)
+    assert n_full > 4 and len(merged) == min(k, n_full)
+    assert merged.tobytes() == full[:len(merged)].tobytes()

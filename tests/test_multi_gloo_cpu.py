@@ -1,0 +1,77 @@
+"""world_size-2 gloo tests of the N > 1 path (no GPU): template-sharded matching = per-rank match
+on a contiguous slice of the bank + all-gather of fixed-size top-k records + exact merge, must
+equal one Detector::match over the whole bank; and the frame-sharded split used by bench.py.
+The per-rank matcher here is the oracle (tests may use it); on the GPU box the same host logic
+runs with the HIP detector and backend "nccl" (RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_py as O
+    from fealess_amd import synth
+    from fealess_amd import distributed as D
+    from fealess_amd.api import merge_topk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(99)                       # same frame + bank on every rank
+    w0, h0, T = 320, 160, [5, 8]
+    qs = [synth.random_quantized(rng, w0 >> l, h0 >> l, 0.04) for l in range(2) for _ in range(2)]
+    bank = synth.make_bank("obj", 41, 2, 2, w0, h0, seed=17, qs=qs, planted_frac=0.5, bbox=64)
+    shard, first = D.shard_bank(bank, world, rank)
+    local, _ = O.match_quantized(qs, w0, h0, T, [shard], 55.0)
+    gathered = D.allgather_records(D.pad_topk(local, k, first), dist)
+    merged = merge_topk(gathered, k)
+    full, n_full = O.match_quantized(qs, w0, h0, T, [bank], 55.0)
+    ok = len(merged) == min(k, n_full) and merged.tobytes() == full[:len(merged)].tobytes() and n_full > 8
+    # frame-sharded: disjoint, complete cover
+    f0, fc = D.shard_range(37, world, rank)
+    import torch
+    cover = torch.zeros(37, dtype=torch.int32)
+    cover[f0:f0 + fc] = 1
+    dist.all_reduce(cover)
+    ok = ok and bool((cover == 1).all())
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(f"{int(ok)} {len(merged)} {n_full}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [8, 64])
+def test_template_sharded_allgather_merge_equals_global(tmp_path, k):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, k, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok, n_m, n_full = open(tmp_path / f"rank{r}.txt").read().split()
+        assert ok == "1", (r, n_m, n_full)
+
+
+def test_shard_range_properties():
+    sys.path.insert(0, ROOT)
+    from fealess_amd.distributed import shard_range
+    for n in (0, 1, 7, 16000, 2001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (a, ca), (b, _) in zip(spans, spans[1:]):
+                assert a + ca == b
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1

@@ -1,0 +1,281 @@
+"""CPU tests of the ORACLE (oracle/liboracle.so): tables vs the reference text (when present),
+independent naive re-derivations on tiny inputs, hand-worked known answers, domain properties,
+and the committed golden fixtures.  No GPU needed.
+
+The reference holds no tests or golden vectors for this path, so nothing
+here can pin the oracle to the reference's *outputs*: "parity unpinned".  What is pinned: the two
+data tables against the reference's own text, the algorithm against independent formulations,
+and the oracle against its committed fixtures.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from fealess_amd import synth
+from fealess_amd.bank import TemplateBank
+
+REF = "/root/reference"
+
+
+# ---- tables ------------------------------------------------------------------------------------
+def test_similarity_lut_rule(oracle):
+    lut = oracle.similarity_lut()
+    for ori in range(8):
+        for byte in range(256):
+            a = lut[32 * ori + (byte & 15)]
+            b = lut[32 * ori + 16 + (byte >> 4)]
+            assert max(a, b) == util.naive_response(byte, ori)
+    # golden digest so the table cannot drift silently where the reference is absent
+    assert int(lut.astype(np.int64).sum()) == 460 and int((lut.astype(np.int64) * np.arange(256)).sum()) == 59268
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference text not available on this box")
+def test_tables_equal_reference_text(oracle):
+    src = open(os.path.join(REF, "linemod", "linemod.cpp"), errors="replace").read()
+    line = [l for l in src.splitlines() if l.startswith("CV_DECL_ALIGNED(16) static const unsigned char SIMILARITY_LUT")][0]
+    ref_lut = np.array([int(v) for v in re.findall(r"\d+", line[line.index("{"):])], np.uint8)
+    assert ref_lut.size == 256 and np.array_equal(ref_lut, oracle.similarity_lut())
+    txt = open(os.path.join(REF, "linemod", "normal_lut.i")).read()
+    nums = [int(v) for v in re.findall(r"\d+", txt[txt.index("{"):])]
+    assert np.array_equal(np.array(nums[:8000], np.uint8), oracle.normal_lut())
+
+
+def test_normal_lut_digest(oracle):
+    lut = oracle.normal_lut().reshape(20, 20, 20)
+    assert all(np.array_equal(lut[z], lut[0]) for z in range(20))
+    vals, counts = np.unique(lut, return_counts=True)
+    assert dict(zip(vals.tolist(), counts.tolist())) == {1: 760, 2: 1060, 4: 740, 8: 1160, 16: 920, 32: 1280, 64: 920, 128: 1160}
+
+
+# ---- scan stages vs naive formulations ---------------------------------------------------------
+@pytest.mark.parametrize("T", [2, 4, 5])
+def test_spread_and_response_vs_naive(oracle, T):
+    rng = np.random.default_rng(T)
+    q = synth.random_quantized(rng, 20 * T // T * 4, 12, 0.3)[:12, :16]
+    q = np.ascontiguousarray(q)
+    sp = oracle.spread(q, T)
+    assert np.array_equal(sp, util.naive_spread(q, T))
+    maps = oracle.response_maps(sp)
+    for ori in range(8):
+        exp = np.vectorize(lambda b: util.naive_response(int(b), ori))(sp)
+        assert np.array_equal(maps[ori], exp)
+
+
+def test_linear_memory_layout(oracle):
+    rng = np.random.default_rng(3)
+    T, w, h = 4, 32, 16
+    q = synth.random_quantized(rng, w, h, 0.3)
+    lm = oracle.build_linear_memories(q, T)
+    sp = oracle.spread(q, T)
+    maps = oracle.response_maps(sp)
+    W, H = w // T, h // T
+    for lab in (0, 5):
+        for y in range(h):
+            for x in range(w):
+                assert lm[lab, ((y % T) * T + x % T) * W * H + (y // T) * W + x // T] == maps[lab, y, x]
+    assert not lm[:, T * T * W * H:].any()          # zero pad
+
+
+def test_similarity_vs_naive_including_wrap_and_overread(oracle):
+    rng = np.random.default_rng(8)
+    T, w, h = 4, 48, 32
+    q = synth.random_quantized(rng, w, h, 0.4)
+    lm = oracle.build_linear_memories(q, T)
+    for (width, height, feats) in [
+        (12, 8, [(0, 0, 1), (5, 3, 6), (11, 7, 2), (3, 8, 4)]),       # y == height == 8, 8 % 4 == 0: over-read (Q2)
+        (20, 13, [(19, 12, 0), (7, 2, 3), (-1, 2, 3), (60, 1, 2)]),    # out-of-image features skipped
+        (47, 31, [(0, 0, 7)]),                                         # a single template position
+    ]:
+        b = TemplateBank("o", 1, 1)
+        b.add_pyramid([dict(width=width, height=height, offset_x=0, offset_y=0, pyramid_level=0,
+                            features=np.array(feats, np.int32))])
+        got = oracle.total_similarity([lm], b, 0, w, h, T)
+        assert np.array_equal(got, util.naive_similarity(q, T, feats, width, height))
+
+
+def test_match_known_answer_single_level(oracle):
+    """Hand-worked: one orientation-0 pixel at (x, y) = (12, 9); a one-feature template (label 0,
+    feature at its origin) of size 4x4; T = 4.  spread (anchored top-left) sets bit 0 on
+    x in 9..12, y in 6..9; response 4 there.  Template position (c, r) samples (4c, 4r): only
+    (12, 8) = (c, r) = (3, 2) lies inside.  raw threshold for 80 %: (int)(2 + 0.8*2 + 0.5) = 4 and
+    4 > 4 is false: no match; at 70 %: (int)(2 + 1.4 + 0.5) = 3 -> one match at
+    (c*T + T/2 - 1, r*T + T/2 - 1) = (13, 9) with similarity 4*100/4 + 0.5 = 100.5 (Q3)."""
+    q = np.zeros((16, 24), np.uint8)
+    q[9, 12] = 1
+    b = TemplateBank("o", 1, 1)
+    b.add_pyramid([dict(width=4, height=4, offset_x=0, offset_y=0, pyramid_level=0, features=np.array([[0, 0, 0]], np.int32))])
+    m, n = oracle.match_quantized([q], 24, 16, [4], [b], 80.0)
+    assert n == 0
+    m, n = oracle.match_quantized([q], 24, 16, [4], [b], 70.0)
+    assert n == 1
+    assert (int(m[0]["x"]), int(m[0]["y"])) == (13, 9)
+    assert m[0]["similarity"] == np.float32(100.5)
+    sim = oracle.total_similarity([oracle.build_linear_memories(q, 4)], b, 0, 24, 16, 4)
+    assert sim[2, 3] == 4 and sim.sum() == 4
+
+
+def test_sort_unique_semantics(oracle):
+    """Match::operator< orders by similarity desc then template_id asc; operator== ignores the
+    template id (linemod.hpp:262-274): equal (x, y, sim) from adjacent templates collapse."""
+    rng = np.random.default_rng(5)
+    qs = [synth.random_quantized(rng, 160 >> l, 128 >> l, 0.05) for l in range(2)]
+    bank = synth.make_bank("o", 6, 2, 1, 160, 128, seed=2, qs=qs, planted_frac=1.0, bbox=48)
+    t, f, p = bank.arrays()
+    dup = TemplateBank("o", 2, 1)          # every pyramid twice -> identical matches, different ids
+    for i in range(6):
+        for _ in range(2):
+            tl = []
+            for k in range(2):
+                hdr = t[i * 2 + k]
+                fr = f[hdr["feat_begin"]:hdr["feat_begin"] + hdr["feat_count"]]
+                tl.append(dict(width=int(hdr["width"]), height=int(hdr["height"]), offset_x=int(hdr["offset_x"]),
+                               offset_y=int(hdr["offset_y"]), pyramid_level=k, features=np.stack([fr["x"], fr["y"], fr["label"]], 1)))
+            dup.add_pyramid(tl)
+    m1, n1 = oracle.match_quantized(qs, 160, 128, [4, 8], [bank], 80.0)
+    m2, n2 = oracle.match_quantized(qs, 160, 128, [4, 8], [dup], 80.0)
+    assert n1 > 0
+    sim = m2["similarity"]
+    assert np.all(sim[:-1] >= sim[1:])
+    key = lambda m: sorted({(int(a["x"]), int(a["y"]), float(a["similarity"])) for a in m})
+    assert key(m1) == key(m2)
+    same = (m2["x"][1:] == m2["x"][:-1]) & (m2["y"][1:] == m2["y"][:-1]) & (sim[1:] == sim[:-1])
+    assert not same.any()                  # adjacent duplicates removed
+
+
+# ---- front-end properties ----------------------------------------------------------------------
+def test_fast_atan2_accuracy_and_quadrants(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        x, y = rng.integers(-1020, 1021, 2)
+        if x == 0 and y == 0:
+            continue
+        a = oracle.lib().orc_fast_atan2(float(y), float(x))
+        t = np.degrees(np.arctan2(y, x)) % 360.0
+        assert abs(((a - t + 180) % 360) - 180) < 0.35
+    assert oracle.lib().orc_fast_atan2(0.0, 0.0) == 0.0
+
+
+def test_orientation_of_a_vertical_edge(oracle):
+    bgr = np.zeros((40, 60, 3), np.uint8)
+    bgr[:, 30:] = 200                                   # dx > 0 -> 0 deg -> bin 0 -> bit 1
+    q = oracle.quantized_orientations(bgr, 10.0)
+    assert set(np.unique(q)) == {0, 1}
+    assert q[5:35, 27:33].any() and not q[:, :20].any()
+    bgr2 = np.ascontiguousarray(bgr.transpose(1, 0, 2))  # horizontal edge: 90 deg -> bin 4 -> bit 16
+    q2 = oracle.quantized_orientations(bgr2, 10.0)
+    vals, counts = np.unique(q2, return_counts=True)
+    assert set(vals) <= {0, 1, 16} and dict(zip(vals.tolist(), counts.tolist()))[16] >= 250
+
+
+def test_normals_of_planes(oracle):
+    d = np.full((60, 80), 800, np.uint16)
+    q = oracle.quantized_normals(d)
+    inner = q[8:50, 8:70]
+    assert len(np.unique(inner)) == 1 and inner[0, 0] != 0   # fronto-parallel: one label everywhere
+    assert not q[:5].any() and not q[:, :5].any()           # untouched border stays 0
+    ys = np.arange(60)[:, None].repeat(80, 1)
+    up = oracle.quantized_normals((800 + 2 * ys).astype(np.uint16))[8:50, 8:70]
+    down = oracle.quantized_normals((800 - 2 * ys).astype(np.uint16))[8:50, 8:70]
+    assert np.all(up == 4) and np.all(down == 64)          # +y / -y tilt: directions 90 and 270 degrees
+    assert not oracle.quantized_normals(np.full((60, 80), 2100, np.uint16)).any()
+
+
+def test_pyrdown_and_median_properties(oracle):
+    c = np.full((24, 36, 3), 77, np.uint8)
+    assert np.all(oracle.pyrdown_bgr(c) == 77)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (24, 36, 3), dtype=np.uint8)
+    pd = oracle.pyrdown_bgr(img)
+    assert pd.shape == (12, 18, 3)
+    k = np.array([1, 4, 6, 4, 1])
+    acc = 0
+    for j in range(5):
+        for i in range(5):
+            acc += k[j] * k[i] * int(img[2 * 5 + j - 2, 2 * 7 + i - 2, 1])
+    assert pd[5, 7, 1] == (acc + 128) >> 8
+
+
+# ---- ICP / back-projection ---------------------------------------------------------------------
+def test_depth_to_3d_formula(oracle):
+    d = np.array([[0, 1000], [500, 2000]], np.uint16)
+    p = oracle.depth_to_3d(d, 600.0, 500.0, 1.0, 0.5)
+    assert np.isnan(p[0, 0]).all()
+    z = np.float32(1000) * np.float32(0.001)
+    assert p[0, 1, 2] == z and p[0, 1, 0] == (np.float32(1) - np.float32(1.0)) * (np.float32(1) / np.float32(600)) * z
+    assert p[1, 0, 1] == ((np.float32(1) - np.float32(0.5)) * (np.float32(1) / np.float32(500))) * (np.float32(500) * np.float32(0.001))
+
+
+def test_svd3_reconstructs(oracle):
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        A = rng.normal(0, 100, (3, 3)).astype(np.float32)
+        w, u, vt = oracle.svd3(A)
+        assert np.all(w[:-1] >= w[1:])
+        assert np.allclose(u @ np.diag(w) @ vt, A, atol=2e-3 * np.abs(A).max())
+        assert np.allclose(u.T @ u, np.eye(3), atol=1e-4) and np.allclose(vt @ vt.T, np.eye(3), atol=1e-4)
+
+
+def _paired_clouds(seed, n=1200):
+    rng = np.random.default_rng(seed)
+    ref = (rng.normal(0, 1, (n, 3)) * np.array([60, 40, 12]) + np.array([10, -5, 650])).astype(np.float32)
+    dR = synth.rot_z(0.03) @ synth.rot_x(-0.02)
+    c = ref.mean(0)
+    model = ((ref - c) @ dR.T + c + np.array([2.0, -1.0, 1.5])).astype(np.float32)
+    return ref, model, dR
+
+
+def test_icp_recovers_rigid_motion_and_kdtree_equals_brute(oracle):
+    ref, model, dR = _paired_clouds(1)
+    a = oracle.icp(ref, model, 15, 0.0, -3.0e38, use_kdtree=True)
+    b = oracle.icp(ref, model, 15, 0.0, -3.0e38, use_kdtree=False)
+    assert a["iters"] == 15
+    assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["T"], b["T"])
+    moved = model @ a["R"].T + a["T"]
+    before = np.linalg.norm(model - ref, axis=1).mean()
+    after = np.linalg.norm(moved - ref, axis=1).mean()
+    assert after < 0.5 * before and abs(float(a["dist_mean"]) - after) < 0.5
+    assert np.abs(a["R"] - dR.T).max() < 5e-2
+    c = oracle.icp(ref, model, 15, 0.0, -3.0e38, accum64=True)
+    assert np.abs(c["R"] - a["R"]).max() < 5e-3       # float32 summation noise of the reference itself
+
+
+def test_icp_reference_quirks(oracle):
+    ref, model, _ = _paired_clouds(2, 300)
+    r = oracle.icp(ref[:2], model[:2], 5)
+    assert r["rc"] == -1 and r["dist_mean"] == -1.0 and not r["R"].any()        # < 3 points (ICP.cpp:633-638)
+    r = oracle.icp(ref, model, 10, 0.5, 0.01)                                   # CadReco defaults: early exit
+    assert 1 <= r["iters"] <= 10
+    far = model.copy()
+    far[:, 0] += 400.0
+    r = oracle.icp(ref, far, 6, 0.0, -3.0e38)
+    assert r["iters"] == 6
+
+
+# ---- golden fixtures: the oracle must keep producing what was committed ---------------------------
+def test_golden_linemod(oracle):
+    g = util.golden("linemod_320x160.npz")
+    bank = util.bank_from_arrays(g["templates"], g["features"], g["poses"], 2, 2)
+    qs = [g["q0"], g["q1"], g["q2"], g["q3"]]
+    m, n = oracle.match_quantized(qs, 320, 160, [5, 8], [bank], float(g["threshold"]))
+    assert n == int(g["n_matches"]) and m.tobytes() == g["matches"].tobytes()
+    lms = [oracle.build_linear_memories(qs[2 + k], 8) for k in range(2)]
+    for i in range(bank.n_pyramids):
+        assert np.array_equal(oracle.total_similarity(lms, bank, i, 160, 80, 8), g["sims"][i])
+
+
+def test_golden_frontend_icp_recognition(oracle):
+    g = util.golden("frontend_256x192.npz")
+    assert np.array_equal(oracle.quantized_orientations(g["bgr"], 10.0), g["qo"])
+    assert np.array_equal(oracle.quantized_normals(g["depth"]), g["qn"])
+    assert np.array_equal(oracle.pyrdown_bgr(g["bgr"]), g["pyrdown"])
+    g = util.golden("icp_1500.npz")
+    r = oracle.icp(g["ref"], g["model"], 12, 0.0, -3.0e38)
+    assert np.array_equal(r["R"], g["R32"]) and np.array_equal(r["T"], g["T32"])
+    g = util.golden("recognition_vga.npz")
+    bank = util.bank_from_arrays(g["templates"], g["features"], g["poses"], 2, 2, model_depths=g["model_depths"])
+    r = oracle.recognition(g["bgr"], g["depth"], tuple(g["K"]), [5, 8], bank, 75.0, 10, 0.5, 0.01)
+    assert r["found"] == 1 and np.array_equal(r["pose"], g["pose"])
+    assert [r["best"]["x"], r["best"]["y"], r["best"]["template_id"]] == g["best"].tolist()
