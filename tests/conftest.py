@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime; load it BEFORE libfealess_hip.so (which links the system
+# one) so that tests which hand device buffers between the two (top-k export, RCCL) share one
+# runtime.  The other order leaves torch without a device ("No HIP GPUs are available").
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
