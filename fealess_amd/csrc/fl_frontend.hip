@@ -3,8 +3,9 @@
 //  :434-453 ColorGradientPyramid::pyrDown, :567-685 quantizedNormals, :721-739 NN downsample).
 //
 //   k_color_quantize   GaussianBlur 7x7 -> Sobel x/y -> max-magnitude channel -> fastAtan2 ->
-//                      16-bin quantise -> 3x3 majority vote, fused through LDS tiles: the BGR
-//                      tile is read from HBM once and only the one-hot byte image is written.
+//                      16-bin quantise -> 3x3 majority vote, fused in registers (sliding window per
+//                      column, wave shuffles for x+-1): the BGR image is read from HBM once and only
+//                      the one-hot byte image is written.
 //   k_pyrdown_bgr      cv::pyrDown [1 4 6 4 1]^2, (acc+128)>>8, REFLECT_101
 //   k_normals          bilateral 8-neighbour LSQ normal (int64) + NORMAL_LUT
 //   k_median5          exact 5x5 median of one-hot bytes (replicated border)
@@ -49,92 +50,103 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 // ------------------------------------------------------------------------------------------
-#define CQ_TW 32
-#define CQ_TH 16
-#define CQ_SW (CQ_TW + 10)   // source tile: +-5
-#define CQ_SH (CQ_TH + 10)
-#define CQ_MW (CQ_TW + 4)    // smoothed tile: +-2
-#define CQ_MH (CQ_TH + 4)
-#define CQ_QW (CQ_TW + 2)    // quantised tile: +-1
-#define CQ_QH (CQ_TH + 2)
+// k_color_quantize: one wavefront owns a strip of 64 adjacent image columns (60 outputs plus two
+// halo columns on each side) and walks CQ_CH output rows downwards with the whole filter chain in
+// registers: a 7-row ring of horizontal-blur sums per channel, 3-row rings of the smoothed pixel
+// (packed B|G<<8|R<<16) and of the 16-bin code for x-1, x, x+1 -- horizontal neighbours come from
+// wave shuffles, vertical ones from the rings.  No LDS, no barriers; every source byte is fetched
+// once per strip (plus the 4-column / 10-row halo) through two wide loads per row and lane.
+#define CQ_COLS 60
+#define CQ_CH 60
+
+__device__ __forceinline__ void cq_hrow(const uint8_t *__restrict__ src, int w, int h, int row, int xc, bool interior,
+                                        int *h3)
+{
+  const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
+  const uint8_t *p = src + (size_t)clampi(row, 0, h - 1) * w * 3;
+  int a0 = 0, a1 = 0, a2 = 0;
+  if (interior) {          // wave-uniform: no tap of any lane is clamped and 24 bytes are readable
+    uint32_t wd[6];
+    __builtin_memcpy(wd, p + 3 * (xc - 3), 16);
+    __builtin_memcpy(wd + 4, p + 3 * (xc - 3) + 16, 8);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int b0 = 3 * t, b1 = 3 * t + 1, b2 = 3 * t + 2;
+      a0 += kk[t] * (int)((wd[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu);
+      a1 += kk[t] * (int)((wd[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu);
+      a2 += kk[t] * (int)((wd[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const uint8_t *q = p + 3 * clampi(xc + t - 3, 0, w - 1);       // BORDER_REPLICATE
+      a0 += kk[t] * q[0];
+      a1 += kk[t] * q[1];
+      a2 += kk[t] * q[2];
+    }
+  }
+  h3[0] = a0;
+  h3[1] = a1;
+  h3[2] = a2;
+}
 
 __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restrict__ bgr, size_t in_stride,
                                                         uint8_t *__restrict__ dst, size_t out_stride, int w, int h,
-                                                        float threshold_sq)
+                                                        float threshold_sq, int nstrips, int nchunks)
 {
-  __shared__ uint8_t s_src[CQ_SH][CQ_SW][3];
-  __shared__ uint16_t s_row[CQ_SH][CQ_MW][3];    // horizontal pass, 8 fractional bits (<= 65280)
-  __shared__ uint8_t s_sm[CQ_MH][CQ_MW][3];
-  __shared__ uint8_t s_q[CQ_QH][CQ_QW];
-  __shared__ float s_mag[CQ_TH][CQ_TW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= nstrips * nchunks) return;
+  const int strip = item % nstrips, chunk = item / nstrips;
   const uint8_t *src = bgr + (size_t)blockIdx.z * in_stride;
   uint8_t *out = dst + (size_t)blockIdx.z * out_stride;
-  const int x0 = blockIdx.x * CQ_TW, y0 = blockIdx.y * CQ_TH;
-  const int tid = threadIdx.x;
-  // LDS slot (r, c) of s_src holds image pixel (clamp(y0-5+r), clamp(x0-5+c))
-  for (int i = tid; i < CQ_SH * CQ_SW; i += 256) {
-    const int r = i / CQ_SW, c = i - r * CQ_SW;
-    const int yy = clampi(y0 - 5 + r, 0, h - 1), xx = clampi(x0 - 5 + c, 0, w - 1);
-    const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
-    s_src[r][c][0] = p[0];
-    s_src[r][c][1] = p[1];
-    s_src[r][c][2] = p[2];
-  }
-  __syncthreads();
-  // GaussianBlur 7x7, sigma 0 -> {8,28,56,72,56,28,8}/256 per pass, BORDER_REPLICATE (linemod.cpp:247).
-  // A smoothed sample requested outside the image is the smoothed sample at the clamped
-  // position (that is what Sobel's own BORDER_REPLICATE reads), hence the clamps on the centre.
-  for (int i = tid; i < CQ_SH * CQ_MW; i += 256) {
-    const int r = i / CQ_MW, c = i - r * CQ_MW;
-    const int xc = clampi(x0 - 2 + c, 0, w - 1);
-    int acc0 = 0, acc1 = 0, acc2 = 0;
-    const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
+  const int x = strip * CQ_COLS + lane - 2;
+  // a sample requested outside the image is the sample at the clamped position -- for the blur's own
+  // taps and for Sobel's BORDER_REPLICATE on the *smoothed* image alike (linemod.cpp:247-249)
+  const int xc = clampi(x, 0, w - 1);
+  const int y0 = chunk * CQ_CH, y1 = min(h, y0 + CQ_CH);
+  const bool interior = __all(xc >= 3 && xc <= w - 5);
+  const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
+
+  int H[7][3];
+  int center = clampi(y0 - 2, 0, h - 1);
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      const int cc = clampi(xc + t - 3, 0, w - 1) - (x0 - 5);
-      acc0 += kk[t] * s_src[r][cc][0];
-      acc1 += kk[t] * s_src[r][cc][1];
-      acc2 += kk[t] * s_src[r][cc][2];
-    }
-    s_row[r][c][0] = (uint16_t)acc0;
-    s_row[r][c][1] = (uint16_t)acc1;
-    s_row[r][c][2] = (uint16_t)acc2;
-  }
-  __syncthreads();
-  for (int i = tid; i < CQ_MH * CQ_MW; i += 256) {
-    const int r = i / CQ_MW, c = i - r * CQ_MW;
-    const int yc = clampi(y0 - 2 + r, 0, h - 1);
-    int acc0 = 0, acc1 = 0, acc2 = 0;
-    const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
+  for (int i = 0; i < 7; ++i) cq_hrow(src, w, h, center + i - 3, xc, interior, H[i]);
+  uint32_t Sl[3] = {0, 0, 0}, Sc[3] = {0, 0, 0}, Sr[3] = {0, 0, 0};
+  uint32_t Qp[3] = {0, 0, 0};
+  float Mg[3] = {0.f, 0.f, 0.f};
+  for (int yv = y0 - 2; yv <= y1 + 1; ++yv) {
+    const int c = clampi(yv, 0, h - 1);
+    if (c != center) {                                 // advance the 7-row window by one source row
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
-      const int rr = clampi(yc + t - 3, 0, h - 1) - (y0 - 5);
-      acc0 += kk[t] * s_row[rr][c][0];
-      acc1 += kk[t] * s_row[rr][c][1];
-      acc2 += kk[t] * s_row[rr][c][2];
+      for (int i = 0; i < 6; ++i) { H[i][0] = H[i + 1][0]; H[i][1] = H[i + 1][1]; H[i][2] = H[i + 1][2]; }
+      cq_hrow(src, w, h, c + 3, xc, interior, H[6]);
+      center = c;
     }
-    s_sm[r][c][0] = (uint8_t)((acc0 + (1 << 15)) >> 16);
-    s_sm[r][c][1] = (uint8_t)((acc1 + (1 << 15)) >> 16);
-    s_sm[r][c][2] = (uint8_t)((acc2 + (1 << 15)) >> 16);
-  }
-  __syncthreads();
-  // Sobel 3x3 -> strongest channel -> phase -> 16 bins (:248-303, :314); quantised tile +-1
-  for (int i = tid; i < CQ_QH * CQ_QW; i += 256) {
-    const int r = i / CQ_QW, c = i - r * CQ_QW;
-    const int y = y0 - 1 + r, x = x0 - 1 + c;
-    uint8_t q = 0;
-    if (y >= 0 && y < h && x >= 0 && x < w) {
-      const int mr = r + 1, mc = c + 1;         // same pixel in s_sm coordinates
-      int bdx = 0, bdy = 0, bmag = 0;
+    // vertical pass + the single rounding of the 8-bit GaussianBlur: (acc + 2^15) >> 16
+    int v0 = 0, v1 = 0, v2 = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { v0 += kk[i] * H[i][0]; v1 += kk[i] * H[i][1]; v2 += kk[i] * H[i][2]; }
+    const uint32_t S = (uint32_t)((v0 + (1 << 15)) >> 16) | ((uint32_t)((v1 + (1 << 15)) >> 16) << 8) |
+                       ((uint32_t)((v2 + (1 << 15)) >> 16) << 16);
+    const uint32_t L = (uint32_t)__shfl_up((int)S, 1, 64), R = (uint32_t)__shfl_down((int)S, 1, 64);
+    Sl[0] = Sl[1]; Sl[1] = Sl[2]; Sl[2] = L;
+    Sc[0] = Sc[1]; Sc[1] = Sc[2]; Sc[2] = S;
+    Sr[0] = Sr[1]; Sr[1] = Sr[2]; Sr[2] = R;
+    if (yv < y0) continue;                             // wave-uniform
+    // Sobel 3x3 at row ys = yv - 1 (rings hold virtual rows ys-1, ys, ys+1), strongest channel,
+    // fastAtan2, 16 bins (:248-303, :314)
+    const int ys = yv - 1;
+    int bdx = 0, bdy = 0, bmag = 0;
+    {
       int dxs[3], dys[3], mags[3];
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-#define SM(rr, cc) ((int)s_sm[rr][cc][ch])
-        const int dx = (SM(mr - 1, mc + 1) - SM(mr - 1, mc - 1)) + 2 * (SM(mr, mc + 1) - SM(mr, mc - 1)) +
-                       (SM(mr + 1, mc + 1) - SM(mr + 1, mc - 1));
-        const int dy = (SM(mr + 1, mc - 1) - SM(mr - 1, mc - 1)) + 2 * (SM(mr + 1, mc) - SM(mr - 1, mc)) +
-                       (SM(mr + 1, mc + 1) - SM(mr - 1, mc + 1));
-#undef SM
+        const int sh = 8 * ch;
+#define PX(v) ((int)(((v) >> sh) & 0xFFu))
+        const int dx = (PX(Sr[0]) - PX(Sl[0])) + 2 * (PX(Sr[1]) - PX(Sl[1])) + (PX(Sr[2]) - PX(Sl[2]));
+        const int dy = (PX(Sl[2]) - PX(Sl[0])) + 2 * (PX(Sc[2]) - PX(Sc[0])) + (PX(Sr[2]) - PX(Sr[0]));
+#undef PX
         dxs[ch] = dx;
         dys[ch] = dy;
         mags[ch] = dx * dx + dy * dy;
@@ -142,47 +154,49 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restric
       if (mags[0] >= mags[1] && mags[0] >= mags[2]) { bdx = dxs[0]; bdy = dys[0]; bmag = mags[0]; }
       else if (mags[1] >= mags[0] && mags[1] >= mags[2]) { bdx = dxs[1]; bdy = dys[1]; bmag = mags[1]; }
       else { bdx = dxs[2]; bdy = dys[2]; bmag = mags[2]; }
-      if (r >= 1 && r <= CQ_TH && c >= 1 && c <= CQ_TW) s_mag[r - 1][c - 1] = (float)bmag;
-      const float ang = fast_atan2_deg((float)bdy, (float)bdx);
-      const float v = ang * (float)(16.0 / 360.0);
-      int qi = __float2int_rn(v);                        // cvRound: round half to even
-      qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
-      // hysteresisGradient :316-335: border rows/cols zeroed, interior folded to 8 bins
-      q = (y == 0 || y == h - 1 || x == 0 || x == w - 1) ? 0 : (uint8_t)(qi & 7);
     }
-    s_q[r][c] = q;
-  }
-  __syncthreads();
-  // 3x3 majority vote (:337-384)
-  for (int i = tid; i < CQ_TH * CQ_TW; i += 256) {
-    const int r = i / CQ_TW, c = i - r * CQ_TW;
-    const int y = y0 + r, x = x0 + c;
-    if (y >= h || x >= w) continue;
-    uint8_t res = 0;
-    if (y >= 1 && y < h - 1 && x >= 1 && x < w - 1 && s_mag[r][c] > threshold_sq) {
-      unsigned hist = 0;                                 // 8 x 4-bit counters
+    const float ang = fast_atan2_deg((float)bdy, (float)bdx);
+    int qi = __float2int_rn(ang * (float)(16.0 / 360.0));        // cvRound: round half to even
+    qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
+    // hysteresisGradient :316-335: border rows/cols zeroed, interior folded to 8 bins
+    const bool inside = ys > 0 && ys < h - 1 && x > 0 && x < w - 1;
+    const uint32_t q = inside ? (uint32_t)(qi & 7) : 0u;
+    const uint32_t ql = (uint32_t)__shfl_up((int)q, 1, 64), qr = (uint32_t)__shfl_down((int)q, 1, 64);
+    Qp[0] = Qp[1]; Qp[1] = Qp[2]; Qp[2] = q | (ql << 8) | (qr << 16);
+    Mg[0] = Mg[1]; Mg[1] = Mg[2]; Mg[2] = (float)bmag;
+    if (yv < y0 + 2) continue;
+    // 3x3 majority vote at row yo = yv - 2 (:337-384)
+    const int yo = yv - 2;
+    if (lane >= 2 && lane < 2 + CQ_COLS && x < w && yo < y1) {
+      uint8_t res = 0;
+      if (yo >= 1 && yo < h - 1 && x >= 1 && x < w - 1 && Mg[1] > threshold_sq) {
+        unsigned hist = 0;                               // 8 x 4-bit counters
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+        for (int r = 0; r < 3; ++r) {
+          hist += 1u << (4 * (Qp[r] & 0xFFu));
+          hist += 1u << (4 * ((Qp[r] >> 8) & 0xFFu));
+          hist += 1u << (4 * ((Qp[r] >> 16) & 0xFFu));
+        }
+        int max_votes = 0, index = -1;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) hist += 1u << (4 * s_q[r + dy][c + dx]);
-      int max_votes = 0, index = -1;
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int v = (hist >> (4 * b)) & 15;
-        if (max_votes < v) { index = b; max_votes = v; }
+        for (int b = 0; b < 8; ++b) {
+          const int v = (hist >> (4 * b)) & 15;
+          if (max_votes < v) { index = b; max_votes = v; }
+        }
+        if (max_votes >= 5) res = (uint8_t)(1 << index);
       }
-      if (max_votes >= 5) res = (uint8_t)(1 << index);
+      out[(size_t)yo * w + x] = res;
     }
-    out[(size_t)y * w + x] = res;
   }
 }
 
 int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst,
                                      size_t out_stride, int n_frames, int w, int h, float weak_threshold)
 {
-  dim3 grid((w + CQ_TW - 1) / CQ_TW, (h + CQ_TH - 1) / CQ_TH, n_frames);
+  const int nstrips = (w + CQ_COLS - 1) / CQ_COLS, nchunks = (h + CQ_CH - 1) / CQ_CH;
+  dim3 grid((nstrips * nchunks + 3) / 4, 1, n_frames);
   hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, ctx->stream, bgr, in_stride, dst, out_stride, w, h,
-                     weak_threshold * weak_threshold);
+                     weak_threshold * weak_threshold, nstrips, nchunks);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }
