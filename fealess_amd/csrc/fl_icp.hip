@@ -28,15 +28,21 @@
 #include <string.h>
 
 #define ICP_BS 256               // threads per frame workgroup = rows per LDS tile
+#ifdef FL_ICP_DEBUG
+#define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
 #define ICP_MAX_THREADS ICP_BS
 
 // HBM layout of one frame's ICP workspace (n = capacity in points):
 //   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
 //   mod   n x 3 f32   model cloud, transformed in place every iteration
 //   sref  n x float4  reference cloud sorted by grid cell, w = original index (bit pattern)
+//   nn     n x i32    nearest reference index j of model point i found last (kept pair: j, dropped: ~j)
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid
 struct IcpWsLayout {
-  size_t ref, mod, sref, cell_start, cell_cur, total;
+  size_t ref, mod, sref, nn, cell_start, cell_cur, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -48,6 +54,7 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.ref = o; o = al256(o + 12 * nn);
   L.mod = o; o = al256(o + 12 * nn);
   L.sref = o; o = al256(o + 16 * nn);
+  L.nn = o; o = al256(o + 4 * nn);
   L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
   L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
   L.total = o;
@@ -92,7 +99,7 @@ struct IcpShared {
   float dist_mean, dist_diff, px, thr;
   int iter, n_corr, go, ok;
   float xmin, ymin, inv_c;
-  int GX, GY;
+  int GX, GY, nsorted;
   float sums[16];
   double dsum[ICP_BS / 64][16];   // [wave][scalar]
   int iscan[ICP_BS / 64 + 1];
@@ -104,12 +111,16 @@ struct IcpShared {
   // +1 column of padding puts the 16 chain lanes on 16 different banks
   float prod[2][16][ICP_BS + 1];
   float dtile[2][ICP_BS];
+#ifdef FL_ICP_DEBUG
+  int dbg[8];
+  long long tacc[8], tlast;
+#endif
 };
 
 __device__ __forceinline__ bool vvalid(float z) { return z <= 900.0f; }      // common.cpp:261-266
 
 // ---- block-level helpers (every thread of the workgroup must call) ---------------------------
-__device__ int block_excl_scan(IcpShared &S, int v, int *total)
+__device__ __forceinline__ int block_excl_scan(IcpShared &S, int v, int *total)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   int inc = v;
@@ -131,7 +142,7 @@ __device__ int block_excl_scan(IcpShared &S, int v, int *total)
   return S.iscan[wave] + inc - v;
 }
 
-__device__ int block_sum_int(IcpShared &S, int v)
+__device__ __forceinline__ int block_sum_int(IcpShared &S, int v)
 {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
@@ -154,7 +165,7 @@ __device__ __forceinline__ double shfl_xor_d(double v, int s)
 // fixed-shape fp64 reduction of NS scalars per thread -> S.sums[k] as float is NOT done here: the
 // caller rounds.  Result (double) valid in thread 0..NS-1's return slot via S.dsum[0][k].
 template <int NS>
-__device__ void block_sum_double(IcpShared &S, double *v)
+__device__ __forceinline__ void block_sum_double(IcpShared &S, double *v)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
@@ -202,7 +213,7 @@ __device__ __forceinline__ void mat_mat(const float *A, const float *B, float *O
 
 // cv::SVD::compute on 3x3 CV_32F: OpenCV JacobiSVDImpl_<float> restated (same text as
 // oracle/icp_oracle.c orc_svd3, which documents the one deviation: hypot -> sqrt(p*p+b*b)).
-__device__ void svd3(const float *A, float *U, float *Vt)
+__device__ __noinline__ void svd3(const float *A, float *U, float *Vt)
 {
   float At[9];
   double W[3];
@@ -332,7 +343,7 @@ __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
   return c;
 }
 
-__device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sref, int *cell_start, int *cell_cur,
+__device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sref, int *cell_start, int *cell_cur,
                            int ncell_max)
 {
   // bounding box of the finite points
@@ -371,7 +382,7 @@ __device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sr
     }
     if (!(xmax >= xmin)) { xmin = xmax = 0.f; ymin = ymax = 0.f; }
     const float dx = xmax - xmin, dy = ymax - ymin;
-    float c = sqrtf((dx * dy) / (float)(n_ref > 0 ? n_ref : 1) * 2.0f);
+    float c = sqrtf((dx * dy) / (float)(n_ref > 0 ? n_ref : 1));   // about one point per cell on a dense surface
     if (!(c > 0.25f)) c = 0.25f;
     int GX, GY;
     for (;;) {
@@ -409,7 +420,7 @@ __device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sr
     if (threadIdx.x == 0) S.ibase += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) cell_start[ncell] = S.ibase;
+  if (threadIdx.x == 0) { cell_start[ncell] = S.ibase; S.nsorted = S.ibase; }
   for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = cell_start[i];
   __syncthreads();
   for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
@@ -422,103 +433,130 @@ __device__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sr
   __syncthreads();
 }
 
-// exact 1-NN within squared distance thr (float compare as the reference's `dists <= dist_thr`)
-__device__ __forceinline__ void nn_query(const IcpShared &S, const float4 *__restrict__ sref,
-                                         const int *__restrict__ cell_start, float qx, float qy, float qz, float thr,
-                                         int *bi, float *bd)
+// ---- exact 1-NN within squared distance thr (float compare as the reference's `dists <= dist_thr`)
+// cell ranges a query has to visit; false if the query cannot have a neighbour at all
+// `bound` (>= the true nearest squared distance, e.g. the distance to last iteration's partner) only
+// shrinks the visited area: every point within sqrt(bound) is still seen, so the result is exact.
+__device__ __forceinline__ bool nn_ranges(const IcpShared &S, float qx, float qy, float qz, float thr, float bound, int *cx0,
+                                          int *cx1, int *cy0, int *cy1)
 {
-  int best_i = -1;
-  float best_d = INFINITY;
-  if (thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
-    // conservative search radius: float rounding of d2 and of the differences is far below the margin
-    float r = isfinite(thr) ? sqrtf(thr) * 1.0001f + 1e-3f : INFINITY;
-    int cx0 = 0, cx1 = S.GX - 1, cy0 = 0, cy1 = S.GY - 1;
-    if (isfinite(r)) {
-      cx0 = cell_of(qx - r, S.xmin, S.inv_c, S.GX);
-      cx1 = cell_of(qx + r, S.xmin, S.inv_c, S.GX);
-      cy0 = cell_of(qy - r, S.ymin, S.inv_c, S.GY);
-      cy1 = cell_of(qy + r, S.ymin, S.inv_c, S.GY);
+  if (!(thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
+  // conservative search radius: float rounding of d2 and of the differences is far below the margin
+  const float lim = bound < thr ? bound : thr;           // NaN bound -> thr
+  const float r = isfinite(lim) ? sqrtf(lim) * 1.0001f + 1e-3f : INFINITY;
+  *cx0 = 0; *cx1 = S.GX - 1; *cy0 = 0; *cy1 = S.GY - 1;
+  if (isfinite(r)) {
+    *cx0 = cell_of(qx - r, S.xmin, S.inv_c, S.GX);
+    *cx1 = cell_of(qx + r, S.xmin, S.inv_c, S.GX);
+    *cy0 = cell_of(qy - r, S.ymin, S.inv_c, S.GY);
+    *cy1 = cell_of(qy + r, S.ymin, S.inv_c, S.GY);
+  }
+  return true;
+}
+
+// Branch-free running minimum: (d2, index) packed as d2's bit pattern (non-negative floats order
+// like unsigned integers) in the high word and the reference index in the low word, so one
+// 64-bit unsigned min implements "smaller distance, ties to the lower index" exactly.
+#define NN_CONSIDER(P)                                                                            \
+  {                                                                                               \
+    const float dx = qx - (P).x, dy = qy - (P).y, dz = qz - (P).z;                                \
+    float d = dx * dx; /* cvflann::L2_Simple<float> */                                            \
+    d += dy * dy;                                                                                 \
+    d += dz * dz;                                                                                 \
+    const unsigned long long key_ =                                                               \
+        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int((P).w);         \
+    best = key_ < best ? key_ : best;                                                             \
+  }
+#define NN_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+#define NN_UNPACK(best, bi, bd)                                            \
+  {                                                                        \
+    const bool found_ = (best) != NN_KEY_NONE;                             \
+    *(bi) = found_ ? (int)((best) & 0xFFFFFFFFull) : -1;                   \
+    *(bd) = found_ ? __uint_as_float((unsigned)((best) >> 32)) : NAN;      \
+  }
+
+// search of the cell rows [cy0, cy1] x [cx0, cx1]; the grid and the sorted cloud are L2-resident
+__device__ __forceinline__ void nn_search_global(const IcpShared &S, const float4 *__restrict__ sref,
+                                                 const int *__restrict__ cell_start, float qx, float qy, float qz, int cx0,
+                                                 int cx1, int cy0, int cy1, int *bi, float *bd)
+{
+  unsigned long long best = NN_KEY_NONE;
+  // Loads are issued in batches (4 row headers, then 4 candidates) before anything is consumed:
+  // the search is latency-bound, and clamped duplicate candidates cannot change the result.
+  for (int cy = cy0; cy <= cy1; cy += 4) {
+    int rb[4], re[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cyu = min(cy + u, cy1);
+      rb[u] = cell_start[cyu * S.GX + cx0];             // cells of a row are contiguous
+      re[u] = cell_start[cyu * S.GX + cx1 + 1];
     }
-    // Loads are issued in batches (4 row headers, then 8 candidates) before anything is consumed:
-    // the search is latency-bound, and clamped duplicate candidates cannot change the result.
-    for (int cy = cy0; cy <= cy1; cy += 4) {
-      int rb[4], re[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int cyu = min(cy + u, cy1);
-        rb[u] = cell_start[cyu * S.GX + cx0];           // cells of a row are contiguous
-        re[u] = cell_start[cyu * S.GX + cx1 + 1];
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int b = rb[u], e = cy + u <= cy1 ? re[u] : rb[u];   // predicated, keeps rb/re in registers
+      for (int s = b; s < e; s += 4) {
+        float4 p[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (cy + u > cy1) break;
-        const int b = rb[u], e = re[u];
-        for (int s = b; s < e; s += 8) {
-          float4 p[8];
+        for (int v = 0; v < 4; ++v) p[v] = sref[min(s + v, e - 1)];
 #pragma unroll
-          for (int v = 0; v < 8; ++v) p[v] = sref[min(s + v, e - 1)];
-#pragma unroll
-          for (int v = 0; v < 8; ++v) {
-            const float dx = qx - p[v].x, dy = qy - p[v].y, dz = qz - p[v].z;
-            float d = dx * dx;                          // cvflann::L2_Simple<float>
-            d += dy * dy;
-            d += dz * dz;
-            const int j = __float_as_int(p[v].w);
-            if (d < best_d || (d == best_d && j < best_i)) { best_d = d; best_i = j; }
-          }
-        }
+        for (int v = 0; v < 4; ++v) NN_CONSIDER(p[v])
       }
     }
   }
-  *bi = best_i;
-  *bd = best_i >= 0 ? best_d : NAN;
+  NN_UNPACK(best, bi, bd)
 }
 
 // ---- getL2distClouds (ICP.cpp:68-111) over the index-paired clouds, optionally fused with the
-// in-place transformPoints that precedes it (ICP.cpp:28-45, 756).  FL_ICP_PARITY: the per-point
-// terms go through double-buffered LDS tiles and one lane adds them in index order (the
-// reference's `dist_mean += dist` chain) while the other waves already compute the next tile.
-__device__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, float thr, int mode, const float *Ropt,
+// in-place transformPoints that precedes it (ICP.cpp:28-45, 756).  FL_ICP_PARITY: waves 1-3 write
+// the per-point terms into double-buffered LDS tiles while lane 0 of wave 0 adds the previous tile
+// in index order (the reference's `dist_mean += dist` chain); one barrier per tile.
+__device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, float thr, int mode, const float *Ropt,
                              const float *Topt)
 {
+  const bool parity = mode == FL_ICP_PARITY;
+  const int TQ = parity ? ICP_BS - 64 : ICP_BS;          // rows per tile: wave 0 only chains in parity mode
+  const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
   int counter = 0, inl = 0;
   double dsum[1] = {0.0};
   float acc = 0.0f;
-  const int ntiles = (n + ICP_BS - 1) / ICP_BS;
+  const int ntiles = (n + TQ - 1) / TQ;
   for (int t = 0; t < ntiles; ++t) {
-    const int i = t * ICP_BS + threadIdx.x;
-    float term = 0.0f;
-    if (i < n) {
-      float a[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]};
-      if (Ropt && vvalid(a[2])) {                         // transformPoints in place (:28-45, :756)
-        float o[3];
-        mat_vec(Ropt, a, o);
-        a[0] = o[0] + Topt[0];
-        a[1] = o[1] + Topt[1];
-        a[2] = o[2] + Topt[2];
-        mod[3 * i] = a[0];
-        mod[3 * i + 1] = a[1];
-        mod[3 * i + 2] = a[2];
+    if (slot >= 0) {
+      const int i = t * TQ + slot;
+      float term = 0.0f;
+      if (i < n) {
+        float a[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]};
+        if (Ropt && vvalid(a[2])) {                       // transformPoints in place (:28-45, :756)
+          float o[3];
+          mat_vec(Ropt, a, o);
+          a[0] = o[0] + Topt[0];
+          a[1] = o[1] + Topt[1];
+          a[2] = o[2] + Topt[2];
+          mod[3 * i] = a[0];
+          mod[3 * i + 1] = a[1];
+          mod[3 * i + 2] = a[2];
+        }
+        const float b0 = ref[3 * i], b1 = ref[3 * i + 1], b2 = ref[3 * i + 2];
+        if (vvalid(b2) && vvalid(a[2])) {
+          const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
+          // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
+          const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+          if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
+          ++counter;
+        }
       }
-      const float b0 = ref[3 * i], b1 = ref[3 * i + 1], b2 = ref[3 * i + 2];
-      if (vvalid(b2) && vvalid(a[2])) {
-        const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
-        // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
-        const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
-        if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
-        ++counter;
-      }
+      if (parity) S.dtile[t & 1][slot] = term;            // non-inliers add an exact +0.0f
+    } else if (t > 0 && threadIdx.x == 0) {
+      acc = chain_tile(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
     }
-    if (mode == FL_ICP_PARITY) {
-      S.dtile[t & 1][threadIdx.x] = term;                // non-inliers add an exact +0.0f
-      __syncthreads();
-      if (threadIdx.x == 0) acc = chain_tile(S.dtile[t & 1], min(ICP_BS, n - t * ICP_BS), acc);
-    }
+    if (parity) __syncthreads();
   }
+  if (parity && ntiles > 0 && threadIdx.x == 0)
+    acc = chain_tile(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
   counter = block_sum_int(S, counter);
   inl = block_sum_int(S, inl);
   float dm;
-  if (mode == FL_ICP_PARITY) {
+  if (parity) {
     if (threadIdx.x == 0) S.sums[0] = acc;
     __syncthreads();
     dm = S.sums[0];
@@ -540,11 +578,12 @@ __device__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, 
 }
 
 // ---- icpCloudToCloud_Ex (ICP.cpp:617-809) --------------------------------------------------------
-__device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model, int it_thr, float dmt,
-                        float ddt, int mode, fl_icp_result *res)
+__device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model,
+                        int it_thr, float dmt, float ddt, int mode, fl_icp_result *res)
 {
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
   float4 *sref = (float4 *)(wsb + L.sref);
+  int *nn = (int *)(wsb + L.nn);
   int *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
 
   if (threadIdx.x == 0) {
@@ -553,6 +592,10 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     S.iter = 0;
     S.n_corr = 0;
     S.px = 0.f;
+#ifdef FL_ICP_DEBUG
+    for (int i = 0; i < 8; ++i) { S.dbg[i] = 0; S.tacc[i] = 0; }
+    S.tlast = clock64();
+#endif
   }
   __syncthreads();
   if (n_model < 3 || n_ref < 3 || n_ref < n_model) {    // :633-638 (n_ref < n_model: reference reads OOB)
@@ -568,9 +611,11 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     return;
   }
   build_grid(S, ref, n_ref, sref, cell_start, cell_cur, L.ncell_max);
+  TSTAMP(0);
   // copyPoints(pts_model, pts_model_tmp) (:666-667): invalid points become Vec3f() = 0
   for (int i = threadIdx.x; i < n_model; i += blockDim.x)
     if (!vvalid(mod[3 * i + 2])) { mod[3 * i] = 0.f; mod[3 * i + 1] = 0.f; mod[3 * i + 2] = 0.f; }
+  for (int i = threadIdx.x; i < n_model; i += blockDim.x) nn[i] = ~i;   // first guess: the index pair (n_ref >= n_model)
   if (threadIdx.x == 0) {
     S.R[0] = S.R[4] = S.R[8] = 1.f;                      // R = eye, T = 0 (:644-645)
     S.dist_diff = FLT_MAX;
@@ -587,60 +632,104 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     const int iter = S.iter;
     const float thr = S.thr;
     const int rows = iter == 1 ? n_ref : n_model;
-    const int ntiles = (rows + ICP_BS - 1) / ICP_BS;
+    const bool parity = mode == FL_ICP_PARITY;
     int kept = 0;
     double ds[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) ds[k] = 0.0;
-    float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
-    for (int t = 0; t < ntiles; ++t) {
-      const int i = t * ICP_BS + threadIdx.x;
-      float m[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
-      bool have_m = false, have_pair = false;
-      if (i < rows) {
-        if (iter == 1) {                                 // :700-704: index pairs, invalid -> 0
-          if (i < n_model) {
-            have_m = true;
-            have_pair = true;
-            if (vvalid(mod[3 * i + 2])) { m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2]; }
-          }
-          if (vvalid(ref[3 * i + 2])) { r[0] = ref[3 * i]; r[1] = ref[3 * i + 1]; r[2] = ref[3 * i + 2]; }
-        } else {                                         // PointsCorresponding :193-279
-          int j;
-          float d;
-          const float qx = mod[3 * i], qy = mod[3 * i + 1], qz = mod[3 * i + 2];
-          nn_query(S, sref, cell_start, qx, qy, qz, thr, &j, &d);
-          if (d <= thr) {
-            have_m = have_pair = true;
-            m[0] = qx; m[1] = qy; m[2] = qz;
-            r[0] = ref[3 * j]; r[1] = ref[3 * j + 1]; r[2] = ref[3 * j + 2];
-            ++kept;
-          }
+    if (iter > 1) {
+      // Phase A1 -- PointsCorresponding (:193-279): all four waves search.  The partner found last
+      // time (initially the index pair) bounds the search radius, so a converging cloud visits
+      // only a handful of candidates per point; the result is still the exact 1-NN.
+      for (int i = threadIdx.x; i < n_model; i += ICP_BS) {
+        const float qx = mod[3 * i], qy = mod[3 * i + 1], qz = mod[3 * i + 2];
+        const int prev = nn[i];
+        const int g = prev >= 0 ? prev : ~prev;
+        float bound;
+        {
+          const float dx = qx - ref[3 * g], dy = qy - ref[3 * g + 1], dz = qz - ref[3 * g + 2];
+          bound = dx * dx;
+          bound += dy * dy;
+          bound += dz * dz;
+        }
+        int cx0, cx1, cy0, cy1, j = -1;
+        float d = NAN;
+        if (nn_ranges(S, qx, qy, qz, thr, bound, &cx0, &cx1, &cy0, &cy1))
+          nn_search_global(S, sref, cell_start, qx, qy, qz, cx0, cx1, cy0, cy1, &j, &d);
+#ifdef FL_ICP_DEBUG
+        atomicAdd(&S.dbg[3], (cx1 - cx0 + 1) * (cy1 - cy0 + 1)); atomicAdd(&S.dbg[4], 1);
+#endif
+        const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
+        if (keep) ++kept;
+        nn[i] = keep ? j : (j >= 0 ? ~j : (prev >= 0 ? ~prev : prev));
+        if (!parity && keep) {
+          const float m[3] = {qx, qy, qz}, r[3] = {ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]};
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) ds[a * 3 + b] += (double)m[a] * (double)r[b];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { ds[9 + q] += (double)m[q]; ds[12 + q] += (double)r[q]; }
         }
       }
-      if (mode == FL_ICP_PARITY) {
-        // dropped pairs contribute an exact +0.0f, so the chains below are branch-free
-        float (*tile)[ICP_BS + 1] = S.prod[t & 1];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) tile[a * 3 + b][threadIdx.x] = have_pair ? m[a] * r[b] : 0.0f;   // (*it_s) * (*it_ref).t()
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { tile[9 + k][threadIdx.x] = have_m ? m[k] : 0.0f; tile[12 + k][threadIdx.x] = r[k]; }
-        __syncthreads();
-        // wave 0, lane k: scalar k of getMean (:8-25) / the covariance loop (:731-735), in row order;
-        // waves 1-3 run ahead into the other buffer meanwhile
-        if (threadIdx.x < 15) acc = chain_tile(tile[threadIdx.x], min(ICP_BS, rows - t * ICP_BS), acc);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) ds[a * 3 + b] += (double)m[a] * (double)r[b] * (have_pair ? 1.0 : 0.0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { ds[9 + k] += have_m ? (double)m[k] : 0.0; ds[12 + k] += (double)r[k]; }
-      }
+      __syncthreads();                                   // nn[] complete
+      TSTAMP(2);
     }
+    // Phase A2 (iteration 1: the only phase): rows in index order.  Parity mode: waves 1-3 write
+    // the 15 scalars of each row into double-buffered LDS tiles, wave 0 adds the previous tile
+    // in row order -- getMean (:8-25) and the covariance loop (:731-735) as 15 float32 chains.
+    const int TQ = parity ? ICP_BS - 64 : ICP_BS;
+    const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+    const int ntiles = (parity || iter == 1) ? (rows + TQ - 1) / TQ : 0;
+    float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
+    for (int t = 0; t < ntiles; ++t) {
+      if (slot >= 0) {
+        const int i = t * TQ + slot;
+        float m[3] = {0.f, 0.f, 0.f}, r[3] = {0.f, 0.f, 0.f};
+        bool have_m = false, have_pair = false;
+        if (i < rows) {
+          if (iter == 1) {                               // :700-704: index pairs, invalid -> 0
+            if (i < n_model) {
+              have_m = true;
+              have_pair = true;
+              if (vvalid(mod[3 * i + 2])) { m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2]; }
+            }
+            if (vvalid(ref[3 * i + 2])) { r[0] = ref[3 * i]; r[1] = ref[3 * i + 1]; r[2] = ref[3 * i + 2]; }
+          } else {
+            const int j = nn[i];
+            if (j >= 0) {
+              have_m = have_pair = true;
+              m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2];
+              r[0] = ref[3 * j]; r[1] = ref[3 * j + 1]; r[2] = ref[3 * j + 2];
+            }
+          }
+        }
+        if (parity) {
+          // dropped pairs contribute an exact +0.0f, so the chains are branch-free
+          float (*tile)[ICP_BS + 1] = S.prod[t & 1];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = have_pair ? m[a] * r[b] : 0.0f;   // (*it_s) * (*it_ref).t()
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = have_m ? m[q] : 0.0f; tile[12 + q][slot] = r[q]; }
+        } else {
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) ds[a * 3 + b] += (double)m[a] * (double)r[b] * (have_pair ? 1.0 : 0.0);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { ds[9 + q] += have_m ? (double)m[q] : 0.0; ds[12 + q] += (double)r[q]; }
+        }
+      } else if (t > 0 && threadIdx.x < 15) {
+        acc = chain_tile(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+      }
+      if (parity) __syncthreads();
+    }
+    if (parity && ntiles > 0 && threadIdx.x < 15)
+      acc = chain_tile(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, rows - (ntiles - 1) * TQ), acc);
     kept = block_sum_int(S, kept);
+    TSTAMP(3);
     const int ncm = iter == 1 ? n_model : kept, ncr = iter == 1 ? n_ref : kept;
     if (threadIdx.x == 0) S.n_corr = ncm;
     if (ncr < 3 || ncm < 3) {                            // :711-715
@@ -678,6 +767,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
       S.ok = finite_all(S.Ropt, 9) && finite_all(S.Topt, 3);                      // checkRange :748
     }
     __syncthreads();
+    TSTAMP(4);
     if (!S.ok) continue;                                 // :749
     float Ro[9], To[3];
     for (int k = 0; k < 9; ++k) Ro[k] = S.Ropt[k];
@@ -685,6 +775,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     const float old_mean = S.dist_mean;
     __syncthreads();
     l2dist_phase(S, mod, ref, n_model, 3 * old_mean, mode, Ro, To);                // :756, :778-780
+    TSTAMP(5);
     if (threadIdx.x == 0) {
       S.dist_diff = old_mean - S.dist_mean;
       float RT[3];                                       // :793-797
@@ -694,6 +785,9 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
     }
     __syncthreads();
   }
+#ifdef FL_ICP_DEBUG
+  if (threadIdx.x == 0 && blockIdx.x == 0) printf("icp dbg: (unused %d %d) cells/query %.1f queries %d GX %d GY %d n %d | cycles grid %lld qorder %lld A1 %lld A2 %lld svd %lld B %lld | stage %lld search %lld | cands %d rowsteps %d wave-iters %d\n", S.dbg[0], S.dbg[1], S.dbg[4] ? (float)S.dbg[3] / S.dbg[4] : 0.f, S.dbg[4], S.GX, S.GY, n_ref, S.tacc[0], S.tacc[1], S.tacc[2], S.tacc[3], S.tacc[4], S.tacc[5], S.tacc[6], S.tacc[7], S.dbg[5], S.dbg[6], S.dbg[7]);
+#endif
   if (threadIdx.x == 0) {
     for (int i = 0; i < 9; ++i) res->R[i] = S.R[i];
     for (int i = 0; i < 3; ++i) res->T[i] = S.T[i];
@@ -706,7 +800,7 @@ __device__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_
 }
 
 // ---- detection() front half: crop back-projection + paired-valid compaction ----------------------
-__device__ int crop_clouds(IcpShared &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
+__device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
                            const int *rm, const int *rr, float *ref, float *mod)
 {
   const int cw = rm[2], ch = rm[3], np = cw * ch;
@@ -752,18 +846,25 @@ __device__ int crop_clouds(IcpShared &S, const IcpArgs &a, const uint16_t *scene
   return S.ibase;
 }
 
+// icpCloudToCloud_Ex on clouds the host staged in the workspace (fl_icp)
+__global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
+{
+  extern __shared__ __align__(16) uint8_t icp_smem[];
+  IcpShared &S = *(IcpShared *)icp_smem;
+  const IcpWsLayout L = icp_layout(a.n_max);
+  uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
+  icp_run(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, a.mode, &a.results[blockIdx.x].det.icp);
+}
+
 __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_pipeline(IcpArgs a)
 {
-  __shared__ IcpShared S;
+  extern __shared__ __align__(16) uint8_t icp_smem[];
+  IcpShared &S = *(IcpShared *)icp_smem;
   const int frame = blockIdx.x;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)frame * a.ws_stride;
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
 
-  if (a.job.kind == 2) {                                 // clouds already staged by the host
-    icp_run(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, a.mode, &a.results[frame].det.icp);
-    return;
-  }
 
   fl_recognition_result *res = &a.results[frame];
   const uint16_t *scene, *model;
@@ -925,6 +1026,21 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
 }
 
 static int icp_threads(int) { return ICP_BS; }
+static size_t icp_lds_bytes() { return (sizeof(IcpShared) + 15) & ~(size_t)15; }
+static int icp_launch(fl_context *ctx, int n_frames, const IcpArgs &a)
+{
+  const size_t lds = icp_lds_bytes();
+  if (a.job.kind == 2) {
+    FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_clouds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_icp_clouds, dim3(n_frames), dim3(icp_threads(n_frames)), lds, ctx->stream, a);
+    FL_HIP(ctx, hipGetLastError());
+    return FL_OK;
+  }
+  FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_pipeline, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_icp_pipeline, dim3(n_frames), dim3(icp_threads(n_frames)), lds, ctx->stream, a);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
 
 extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model, int icp_it_thr,
                       float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem, fl_icp_result *res)
@@ -954,8 +1070,8 @@ extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float 
   a.job.n_ref = n_ref;
   a.job.n_model = n_model;
   a.results = dres;
-  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(ICP_BS), 0, ctx->stream, a);
-  FL_HIP(ctx, hipGetLastError());
+  rc = icp_launch(ctx, 1, a);
+  if (rc) return rc;
   fl_recognition_result *h = nullptr;
   rc = fl_pinned(ctx, sizeof(*h), (void **)&h);
   if (rc) return rc;
@@ -1014,8 +1130,8 @@ extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const 
   a.job.model_depth = dm;
   a.job.scene_depth = dsn;
   a.results = dres;
-  hipLaunchKernelGGL(k_icp_pipeline, dim3(1), dim3(ICP_BS), 0, ctx->stream, a);
-  FL_HIP(ctx, hipGetLastError());
+  rc = icp_launch(ctx, 1, a);
+  if (rc) return rc;
   fl_recognition_result *hres = nullptr;
   rc = fl_pinned(ctx, sizeof(*hres), (void **)&hres);
   if (rc) return rc;
@@ -1060,7 +1176,5 @@ int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsic
   a.poses = det->d_poses;
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = det->d_results;
-  hipLaunchKernelGGL(k_icp_pipeline, dim3(n_frames), dim3(icp_threads(n_frames)), 0, ctx->stream, a);
-  FL_HIP(ctx, hipGetLastError());
-  return FL_OK;
+  return icp_launch(ctx, n_frames, a);
 }
