@@ -510,10 +510,11 @@ __device__ __forceinline__ void nn_search_global(const IcpShared &S, const float
 // in-place transformPoints that precedes it (ICP.cpp:28-45, 756).  FL_ICP_PARITY: waves 1-3 write
 // the per-point terms into double-buffered LDS tiles while lane 0 of wave 0 adds the previous tile
 // in index order (the reference's `dist_mean += dist` chain); one barrier per tile.
-__device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, float thr, int mode, const float *Ropt,
+template <int MODE>
+__device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, float thr, const float *Ropt,
                              const float *Topt)
 {
-  const bool parity = mode == FL_ICP_PARITY;
+  constexpr bool parity = MODE == FL_ICP_PARITY;
   const int TQ = parity ? ICP_BS - 64 : ICP_BS;          // rows per tile: wave 0 only chains in parity mode
   const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
   int counter = 0, inl = 0;
@@ -578,8 +579,9 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
 }
 
 // ---- icpCloudToCloud_Ex (ICP.cpp:617-809) --------------------------------------------------------
+template <int MODE>
 __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model,
-                        int it_thr, float dmt, float ddt, int mode, fl_icp_result *res)
+                        int it_thr, float dmt, float ddt, fl_icp_result *res)
 {
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
   float4 *sref = (float4 *)(wsb + L.sref);
@@ -621,7 +623,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     S.dist_diff = FLT_MAX;
   }
   __syncthreads();
-  l2dist_phase(S, mod, ref, n_model, FLT_MAX, mode, nullptr, nullptr);                  // :670
+  l2dist_phase<MODE>(S, mod, ref, n_model, FLT_MAX, nullptr, nullptr);                  // :670
 
   for (;;) {
     if (threadIdx.x == 0) S.go = (S.dist_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);   // :684
@@ -632,7 +634,8 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     const int iter = S.iter;
     const float thr = S.thr;
     const int rows = iter == 1 ? n_ref : n_model;
-    const bool parity = mode == FL_ICP_PARITY;
+    constexpr bool parity = MODE == FL_ICP_PARITY;
+    constexpr int mode = MODE;
     int kept = 0;
     double ds[15];
 #pragma unroll
@@ -774,7 +777,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     for (int k = 0; k < 3; ++k) To[k] = S.Topt[k];
     const float old_mean = S.dist_mean;
     __syncthreads();
-    l2dist_phase(S, mod, ref, n_model, 3 * old_mean, mode, Ro, To);                // :756, :778-780
+    l2dist_phase<MODE>(S, mod, ref, n_model, 3 * old_mean, Ro, To);                // :756, :778-780
     TSTAMP(5);
     if (threadIdx.x == 0) {
       S.dist_diff = old_mean - S.dist_mean;
@@ -847,15 +850,17 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
 }
 
 // icpCloudToCloud_Ex on clouds the host staged in the workspace (fl_icp)
+template <int MODE>
 __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
-  icp_run(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, a.mode, &a.results[blockIdx.x].det.icp);
+  icp_run<MODE>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
@@ -932,7 +937,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_pipeline(IcpArgs a)
   const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod);
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
-  if (a.mode == FL_ICP_PARITY) {
+  if (MODE == FL_ICP_PARITY) {
     if (threadIdx.x < 64) {
       const int k = threadIdx.x;
       const float acc = chain_sum(k < 3 ? mod : ref, np, 3, k < 3 ? k : k - 3, k < 6);
@@ -963,7 +968,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_pipeline(IcpArgs a)
     mod[3 * i + 2] = o[2] + t_tmp[2];
   }
   __syncthreads();
-  icp_run(S, wsb, L, np, np, a.it_thr, a.dmt, a.ddt, a.mode, &res->det.icp);      // :228
+  icp_run<MODE>(S, wsb, L, np, np, a.it_thr, a.dmt, a.ddt, &res->det.icp);      // :228
   if (threadIdx.x == 0) {
     const fl_icp_result &ic = res->det.icp;
     float Rt[3];
@@ -1027,19 +1032,21 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
 
 static int icp_threads(int) { return ICP_BS; }
 static size_t icp_lds_bytes() { return (sizeof(IcpShared) + 15) & ~(size_t)15; }
-static int icp_launch(fl_context *ctx, int n_frames, const IcpArgs &a)
+template <typename K>
+static int icp_launch_one(fl_context *ctx, K kern, int n_frames, const IcpArgs &a)
 {
   const size_t lds = icp_lds_bytes();
-  if (a.job.kind == 2) {
-    FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_clouds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_icp_clouds, dim3(n_frames), dim3(icp_threads(n_frames)), lds, ctx->stream, a);
-    FL_HIP(ctx, hipGetLastError());
-    return FL_OK;
-  }
-  FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_pipeline, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_icp_pipeline, dim3(n_frames), dim3(icp_threads(n_frames)), lds, ctx->stream, a);
+  FL_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(n_frames), dim3(icp_threads(n_frames)), lds, ctx->stream, a);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
+}
+static int icp_launch(fl_context *ctx, int n_frames, const IcpArgs &a)
+{
+  const bool fast = a.mode == FL_ICP_FAST;
+  if (a.job.kind == 2)
+    return fast ? icp_launch_one(ctx, k_icp_clouds<FL_ICP_FAST>, n_frames, a) : icp_launch_one(ctx, k_icp_clouds<FL_ICP_PARITY>, n_frames, a);
+  return fast ? icp_launch_one(ctx, k_icp_pipeline<FL_ICP_FAST>, n_frames, a) : icp_launch_one(ctx, k_icp_pipeline<FL_ICP_PARITY>, n_frames, a);
 }
 
 extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model, int icp_it_thr,
