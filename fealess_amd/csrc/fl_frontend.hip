@@ -7,8 +7,8 @@
 //                      column, wave shuffles for x+-1): the BGR image is read from HBM once and only
 //                      the one-hot byte image is written.
 //   k_pyrdown_bgr      cv::pyrDown [1 4 6 4 1]^2, (acc+128)>>8, REFLECT_101
-//   k_normals          bilateral 8-neighbour LSQ normal (int64) + NORMAL_LUT
-//   k_median5          exact 5x5 median of one-hot bytes (replicated border)
+//   k_depth_quantize   bilateral 8-neighbour LSQ normal (int64) + NORMAL_LUT + exact 5x5 median of the
+//                      one-hot codes (replicated border), fused in registers like k_color_quantize
 //   k_resize_nn_half   src(2y, 2x)
 //
 // The integer stages are exact; the float stages restate OpenCV 3.x's arithmetic operator by
@@ -212,17 +212,31 @@ __global__ __launch_bounds__(256) void k_pyrdown_bgr(const uint8_t *__restrict__
   uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
   const int k[5] = {1, 4, 6, 4, 1};
   int acc0 = 0, acc1 = 0, acc2 = 0;
+  // interior columns: the 5 taps are 15 contiguous bytes -> one 16-byte load per source row
+  const bool wide = 2 * x - 2 >= 0 && 2 * x + 2 <= w - 1 && 3 * (2 * x - 2) + 16 <= 3 * w;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int yy = reflect101(2 * y + j - 2, h);
     int r0 = 0, r1 = 0, r2 = 0;
+    if (wide) {
+      uint32_t wd[4];
+      __builtin_memcpy(wd, src + ((size_t)yy * w + 2 * x - 2) * 3, 16);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int xx = reflect101(2 * x + i - 2, w);
-      const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
-      r0 += k[i] * p[0];
-      r1 += k[i] * p[1];
-      r2 += k[i] * p[2];
+      for (int i = 0; i < 5; ++i) {
+        const int b0 = 3 * i, b1 = 3 * i + 1, b2 = 3 * i + 2;
+        r0 += k[i] * (int)((wd[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu);
+        r1 += k[i] * (int)((wd[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu);
+        r2 += k[i] * (int)((wd[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int xx = reflect101(2 * x + i - 2, w);
+        const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
+        r0 += k[i] * p[0];
+        r1 += k[i] * p[1];
+        r2 += k[i] * p[2];
+      }
     }
     acc0 += k[j] * r0;
     acc1 += k[j] * r1;
@@ -283,78 +297,102 @@ __device__ __forceinline__ void accum_bilateral(long long delta, long long i, lo
   b[1] += fj * delta;
 }
 
-__global__ __launch_bounds__(256) void k_normals(const uint16_t *__restrict__ depth_, size_t in_stride,
-                                                 uint8_t *__restrict__ dst_, size_t out_stride, int w, int h,
-                                                 int distance_threshold, int difference_threshold)
+// k_depth_quantize: quantizedNormals (linemod.cpp:595-683) fused with the medianBlur(5) that ends
+// it (:684).  Same execution shape as k_color_quantize: a wavefront owns 64 adjacent columns (60
+// outputs + 2 halo columns per side), walks DQ_CH output rows, keeps the last five rows of normal
+// codes in registers and gets the x-2..x+2 neighbours by wave shuffles.  The codes are 0 or one-hot,
+// i.e. 9 classes ordered like their byte values, so the exact 5x5 median is the class where the
+// cumulative count reaches 13: per-column histograms (nine 5-bit fields in a 64-bit word) are summed
+// over the five columns.  The un-medianed normal image never exists in memory.
+#define DQ_COLS 60
+#define DQ_CH 60
+
+__device__ __forceinline__ unsigned dq_normal_class(const uint16_t *__restrict__ depth, int w, int h, int y, int x,
+                                                    int distance_threshold, int difference_threshold)
 {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
-  const uint16_t *depth = depth_ + (size_t)blockIdx.z * in_stride;
-  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
   const int r = 5;
-  uint8_t out = 0;
-  if (y >= r && y < h - r - 1 && x >= r && x < w - r - 1) {               // loop bounds :619, :624
-    const uint16_t *p = depth + (size_t)y * w + x;
-    const long long d = p[0];
-    if (d < distance_threshold) {
-      long long A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
-      accum_bilateral((long long)p[-r - r * w] - d, -r, -r, A, b, difference_threshold);
-      accum_bilateral((long long)p[0 - r * w] - d, 0, -r, A, b, difference_threshold);
-      accum_bilateral((long long)p[+r - r * w] - d, +r, -r, A, b, difference_threshold);
-      accum_bilateral((long long)p[-r] - d, -r, 0, A, b, difference_threshold);
-      accum_bilateral((long long)p[+r] - d, +r, 0, A, b, difference_threshold);
-      accum_bilateral((long long)p[-r + r * w] - d, -r, +r, A, b, difference_threshold);
-      accum_bilateral((long long)p[0 + r * w] - d, 0, +r, A, b, difference_threshold);
-      accum_bilateral((long long)p[+r + r * w] - d, +r, +r, A, b, difference_threshold);
-      const long long det = A[0] * A[3] - A[1] * A[1];
-      const long long ddx = A[3] * b[0] - A[1] * b[1];
-      const long long ddy = -A[1] * b[0] + A[0] * b[1];
-      float nx = (float)(617 * ddx);
-      float ny = (float)(617 * ddy);
-      float nz = (float)(-det * d);
-      const float s = sqrtf(nx * nx + ny * ny + nz * nz);
-      if (s > 0) {
-        const float inv = 1.0f / s;
-        nx *= inv;
-        ny *= inv;
-        nz *= inv;
-        const int v1 = (int)(nx * 10 + 10);
-        const int v2 = (int)(ny * 10 + 10);
-        const int v3 = (int)(nz * 20 + 20);
-        // Q7: v3 == 20 is an out-of-bounds read in the reference; defined as 0 here
-        if (v1 >= 0 && v1 <= 19 && v2 >= 0 && v2 <= 19 && v3 >= 0 && v3 <= 19) out = c_normal_lut[v2 * 20 + v1];
-      }
-    }
-  }
-  dst[(size_t)y * w + x] = out;
+  if (!(y >= r && y < h - r - 1 && x >= r && x < w - r - 1)) return 0;   // loop bounds :619, :624
+  const uint16_t *p = depth + (size_t)y * w + x;
+  const long long d = p[0];
+  if (!(d < distance_threshold)) return 0;
+  long long A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
+  accum_bilateral((long long)p[-r - r * w] - d, -r, -r, A, b, difference_threshold);
+  accum_bilateral((long long)p[0 - r * w] - d, 0, -r, A, b, difference_threshold);
+  accum_bilateral((long long)p[+r - r * w] - d, +r, -r, A, b, difference_threshold);
+  accum_bilateral((long long)p[-r] - d, -r, 0, A, b, difference_threshold);
+  accum_bilateral((long long)p[+r] - d, +r, 0, A, b, difference_threshold);
+  accum_bilateral((long long)p[-r + r * w] - d, -r, +r, A, b, difference_threshold);
+  accum_bilateral((long long)p[0 + r * w] - d, 0, +r, A, b, difference_threshold);
+  accum_bilateral((long long)p[+r + r * w] - d, +r, +r, A, b, difference_threshold);
+  const long long det = A[0] * A[3] - A[1] * A[1];
+  const long long ddx = A[3] * b[0] - A[1] * b[1];
+  const long long ddy = -A[1] * b[0] + A[0] * b[1];
+  float nx = (float)(617 * ddx);
+  float ny = (float)(617 * ddy);
+  float nz = (float)(-det * d);
+  const float s = sqrtf(nx * nx + ny * ny + nz * nz);
+  if (!(s > 0)) return 0;                                  // shadows of the depth sensor
+  const float inv = 1.0f / s;
+  nx *= inv;
+  ny *= inv;
+  nz *= inv;
+  const int v1 = (int)(nx * 10 + 10);
+  const int v2 = (int)(ny * 10 + 10);
+  const int v3 = (int)(nz * 20 + 20);
+  // Q7: v3 == 20 is an out-of-bounds read in the reference; defined as 0 here
+  if (!(v1 >= 0 && v1 <= 19 && v2 >= 0 && v2 <= 19 && v3 >= 0 && v3 <= 19)) return 0;
+  const unsigned v = c_normal_lut[v2 * 20 + v1];
+  return v ? (unsigned)(32 - __clz(v)) : 0u;              // 0 -> 0, 1<<k -> k+1 (ascending in value)
 }
 
-// exact median of 25 bytes that are 0 or one-hot: nine 5-bit counters packed in a 64-bit word
-__global__ __launch_bounds__(256) void k_median5(const uint8_t *__restrict__ src_, size_t in_stride,
-                                                 uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+__global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t *__restrict__ depth_, size_t in_stride,
+                                                        uint8_t *__restrict__ dst_, size_t out_stride, int w, int h,
+                                                        int distance_threshold, int difference_threshold, int nstrips,
+                                                        int nchunks)
 {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
-  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= nstrips * nchunks) return;
+  const int strip = item % nstrips, chunk = item / nstrips;
+  const uint16_t *depth = depth_ + (size_t)blockIdx.z * in_stride;
   uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
-  unsigned long long cnt = 0;
+  const int x = strip * DQ_COLS + lane - 2;
+  const int xc = clampi(x, 0, w - 1);                      // medianBlur replicates the border
+  const int y0 = chunk * DQ_CH, y1 = min(h, y0 + DQ_CH);
+  unsigned ring = 0;                                       // five 4-bit class codes, newest in the low nibble
+  int center = -1;
+  unsigned cls = 0;
+  for (int yv = y0 - 2; yv <= y1 + 1; ++yv) {
+    const int c = clampi(yv, 0, h - 1);
+    if (c != center) {                                     // wave-uniform
+      cls = dq_normal_class(depth, w, h, c, xc, distance_threshold, difference_threshold);
+      center = c;
+    }
+    ring = ((ring << 4) | cls) & 0xFFFFFu;
+    if (yv < y0 + 2) continue;
+    unsigned long long col = 0;                            // column histogram: nine 5-bit counters
 #pragma unroll
-  for (int dy = -2; dy <= 2; ++dy) {
-    const uint8_t *row = src + (size_t)clampi(y + dy, 0, h - 1) * w;
+    for (int k = 0; k < 5; ++k) col += 1ull << (5 * ((ring >> (4 * k)) & 15u));
+    unsigned long long sum = col;
 #pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {
-      const unsigned v = row[clampi(x + dx, 0, w - 1)];
-      const int idx = v ? (32 - __clz(v)) : 0;          // 0 -> 0, 1<<k -> k+1 (ascending in value)
-      cnt += 1ull << (5 * idx);
+    for (int dlt = 1; dlt <= 2; ++dlt) {
+      const int lo = (int)(col & 0xFFFFFFFFull), hi = (int)(col >> 32);
+      const unsigned long long l = (unsigned)__shfl_up(lo, dlt, 64) | ((unsigned long long)(unsigned)__shfl_up(hi, dlt, 64) << 32);
+      const unsigned long long r = (unsigned)__shfl_down(lo, dlt, 64) | ((unsigned long long)(unsigned)__shfl_down(hi, dlt, 64) << 32);
+      sum += l + r;
+    }
+    const int yo = yv - 2;
+    if (lane >= 2 && lane < 2 + DQ_COLS && x < w) {
+      int acc = 0, idx = 0;
+      bool done = false;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        acc += (int)((sum >> (5 * i)) & 31);
+        if (!done && acc >= 13) { idx = i; done = true; }
+      }
+      dst[(size_t)yo * w + x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
     }
   }
-  int acc = 0, idx = 0;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    acc += (int)((cnt >> (5 * i)) & 31);
-    if (acc >= 13) { idx = i; break; }
-  }
-  dst[(size_t)y * w + x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
 }
 
 int fl_launch_quantized_normals(fl_context *ctx, const uint16_t *depth, size_t in_stride, uint8_t *dst,
@@ -363,11 +401,12 @@ int fl_launch_quantized_normals(fl_context *ctx, const uint16_t *depth, size_t i
 {
   int rc = ensure_normal_lut(ctx);
   if (rc) return rc;
-  dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
-  hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, ctx->stream, depth, in_stride / sizeof(uint16_t), tmp, tmp_stride, w,
-                     h, distance_threshold, difference_threshold);
-  FL_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_median5, grid, dim3(256), 0, ctx->stream, (const uint8_t *)tmp, tmp_stride, dst, out_stride, w, h);
+  (void)tmp;
+  (void)tmp_stride;
+  const int nstrips = (w + DQ_COLS - 1) / DQ_COLS, nchunks = (h + DQ_CH - 1) / DQ_CH;
+  dim3 grid((nstrips * nchunks + 3) / 4, 1, n_frames);
+  hipLaunchKernelGGL(k_depth_quantize, grid, dim3(256), 0, ctx->stream, depth, in_stride / sizeof(uint16_t), dst, out_stride,
+                     w, h, distance_threshold, difference_threshold, nstrips, nchunks);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }

@@ -263,6 +263,7 @@ struct RefineArgs {
   size_t lm_off[FL_MAX_MODALITIES];
   size_t off_count, off_cand;
   int M, Lm1, level, w, h, T, W, cap;
+  uint32_t zero_off;         // offset of the zero pad inside a modality's linear memories
   float threshold;
 };
 
@@ -298,13 +299,21 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
       const uint8_t *lm = ws + a.lm_off[m] + row * W + col4;
       const FlFineFeat *ff = a.feat + h.feat_begin;
       uint32_t acc = 0;
-      for (int k = 0; k < h.feat_count; ++k) {
-        const FlFineFeat f = ff[k];
-        const int fx = f.x + offset_x, fy = f.y + offset_y;
-        if (fx < 0 || fy < 0 || fx >= a.w || fy >= a.h) continue;       // :1257 (wave-uniform)
-        uint32_t v;
-        __builtin_memcpy(&v, lm + (uint32_t)(f.lmoff + (uint32_t)shift), 4);
-        acc += v;                                                       // 4 packed u8 adds
+      // 8 features per step, branch-free: a feature that leaves the image (:1257) reads the zero
+      // pad instead, so the 8 loads are independent and in flight together
+      for (int k = 0; k < h.feat_count; k += 8) {
+        uint32_t off[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const FlFineFeat f = ff[min(k + u, h.feat_count - 1)];
+          const int fx = f.x + offset_x, fy = f.y + offset_y;
+          const bool in = (k + u < h.feat_count) && fx >= 0 && fy >= 0 && fx < a.w && fy < a.h;
+          off[u] = in ? (uint32_t)(f.lmoff + (uint32_t)shift) : a.zero_off;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) __builtin_memcpy(&v[u], lm + off[u], 4);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];                          // 4 packed u8 adds each
       }
       tot0 += acc & 0xFFu;
       tot1 += (acc >> 8) & 0xFFu;
@@ -508,6 +517,7 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.T = g.T;
     a.W = g.W;
     a.cap = det->cap;
+    a.zero_off = g.zero_off;
     a.threshold = threshold;
     dim3 grid(n_frames >= 64 ? 32 : 256, n_frames);
     hipLaunchKernelGGL(k_refine, grid, dim3(256), 0, ctx->stream, a);
