@@ -285,11 +285,13 @@ static int ensure_normal_lut(fl_context *ctx)
   return FL_OK;
 }
 
-__device__ __forceinline__ void accum_bilateral(long long delta, long long i, long long j, long long *A, long long *b,
-                                                int threshold)
+// accumBilateral (linemod.cpp:567-579).  The reference accumulates in `long`; with 16-bit depth the
+// sums stay far inside int32 (|A| <= 200, |b| <= 8*5*65535), so 32-bit registers give the same
+// integers; only the final products 617*dd and det*d are widened to 64 bits.
+__device__ __forceinline__ void accum_bilateral(int delta, int i, int j, int *A, int *b, int threshold)
 {
-  const long long f = (delta < 0 ? -delta : delta) < threshold ? 1 : 0;     // linemod.cpp:569
-  const long long fi = f * i, fj = f * j;
+  const int f = (delta < 0 ? -delta : delta) < threshold ? 1 : 0;     // linemod.cpp:569
+  const int fi = f * i, fj = f * j;
   A[0] += fi * i;
   A[1] += fi * j;
   A[3] += fj * j;
@@ -313,23 +315,23 @@ __device__ __forceinline__ unsigned dq_normal_class(const uint16_t *__restrict__
   const int r = 5;
   if (!(y >= r && y < h - r - 1 && x >= r && x < w - r - 1)) return 0;   // loop bounds :619, :624
   const uint16_t *p = depth + (size_t)y * w + x;
-  const long long d = p[0];
+  const int d = p[0];
   if (!(d < distance_threshold)) return 0;
-  long long A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
-  accum_bilateral((long long)p[-r - r * w] - d, -r, -r, A, b, difference_threshold);
-  accum_bilateral((long long)p[0 - r * w] - d, 0, -r, A, b, difference_threshold);
-  accum_bilateral((long long)p[+r - r * w] - d, +r, -r, A, b, difference_threshold);
-  accum_bilateral((long long)p[-r] - d, -r, 0, A, b, difference_threshold);
-  accum_bilateral((long long)p[+r] - d, +r, 0, A, b, difference_threshold);
-  accum_bilateral((long long)p[-r + r * w] - d, -r, +r, A, b, difference_threshold);
-  accum_bilateral((long long)p[0 + r * w] - d, 0, +r, A, b, difference_threshold);
-  accum_bilateral((long long)p[+r + r * w] - d, +r, +r, A, b, difference_threshold);
-  const long long det = A[0] * A[3] - A[1] * A[1];
-  const long long ddx = A[3] * b[0] - A[1] * b[1];
-  const long long ddy = -A[1] * b[0] + A[0] * b[1];
-  float nx = (float)(617 * ddx);
-  float ny = (float)(617 * ddy);
-  float nz = (float)(-det * d);
+  int A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
+  accum_bilateral((int)p[-r - r * w] - d, -r, -r, A, b, difference_threshold);
+  accum_bilateral((int)p[0 - r * w] - d, 0, -r, A, b, difference_threshold);
+  accum_bilateral((int)p[+r - r * w] - d, +r, -r, A, b, difference_threshold);
+  accum_bilateral((int)p[-r] - d, -r, 0, A, b, difference_threshold);
+  accum_bilateral((int)p[+r] - d, +r, 0, A, b, difference_threshold);
+  accum_bilateral((int)p[-r + r * w] - d, -r, +r, A, b, difference_threshold);
+  accum_bilateral((int)p[0 + r * w] - d, 0, +r, A, b, difference_threshold);
+  accum_bilateral((int)p[+r + r * w] - d, +r, +r, A, b, difference_threshold);
+  const int det = A[0] * A[3] - A[1] * A[1];
+  const int ddx = A[3] * b[0] - A[1] * b[1];              // |.| <= 2 * 200 * 2.6e6 < 2^31
+  const int ddy = -A[1] * b[0] + A[0] * b[1];
+  float nx = (float)(617LL * ddx);
+  float ny = (float)(617LL * ddy);
+  float nz = (float)(-(long long)det * d);
   const float s = sqrtf(nx * nx + ny * ny + nz * nz);
   if (!(s > 0)) return 0;                                  // shadows of the depth sensor
   const float inv = 1.0f / s;
