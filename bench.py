@@ -189,8 +189,19 @@ def main():
     }
     dom = max(kern, key=lambda k: kern[k]["ms"])
     ach = kern[dom]["bytes"] / (kern[dom]["ms"] * 1e-3) / 1e9 if kern[dom]["ms"] > 0 else 0.0
+    # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE, separate passes, same command); only quoted when the workload matches
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_b1024.json")))
+        if pm["batch"] == B and pm["templates"] == bank.n_pyramids and args.icp_mode == "parity":
+            kd = pm["kernels"][dom if dom != "k_icp_pipeline" else "k_icp_pipeline<0>"]
+            traffic = dict(fetch_bytes=kd["FETCH_SIZE"] * 1024, write_bytes=kd["WRITE_SIZE"] * 1024, unit="bytes/launch",
+                           note="raw rocprofv3 counters; gfx950 FETCH_SIZE under-counts wide coalesced reads by up to 2x")
+    except Exception:
+        traffic = None
     roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
                     launch_ms=round(kern[dom]["ms"], 4), algorithmic_bytes_per_launch=kern[dom]["bytes"])
     scan_ach = scan_bytes / (times["scan_ms"] * 1e-3) / 1e9 if times["scan_ms"] > 0 else 0.0
 
@@ -215,7 +226,7 @@ def main():
             "scan_kernel": {"achieved_GBs": round(scan_ach, 1), "frac": round(scan_ach / HBM_PEAK_GBS, 4),
                             "note": "algorithmic bytes; linear memories are L2-resident so this may exceed HBM peak"},
         }
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, bank, scenes)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)

@@ -467,6 +467,16 @@ __device__ __forceinline__ bool nn_ranges(const IcpShared &S, float qx, float qy
         ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int((P).w);         \
     best = key_ < best ? key_ : best;                                                             \
   }
+#define NN_CONSIDER_IF(P, PRED)                                                                   \
+  {                                                                                               \
+    const float dx = qx - (P).x, dy = qy - (P).y, dz = qz - (P).z;                                \
+    float d = dx * dx;                                                                            \
+    d += dy * dy;                                                                                 \
+    d += dz * dz;                                                                                 \
+    const unsigned long long key_ =                                                               \
+        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int((P).w);         \
+    best = ((PRED) && key_ < best) ? key_ : best;                                                 \
+  }
 #define NN_KEY_NONE 0xFFFFFFFFFFFFFFFFull
 #define NN_UNPACK(best, bi, bd)                                            \
   {                                                                        \
@@ -481,8 +491,11 @@ __device__ __forceinline__ void nn_search_global(const IcpShared &S, const float
                                                  int cx1, int cy0, int cy1, int *bi, float *bd)
 {
   unsigned long long best = NN_KEY_NONE;
-  // Loads are issued in batches (4 row headers, then 4 candidates) before anything is consumed:
-  // the search is latency-bound, and clamped duplicate candidates cannot change the result.
+  const int last = S.nsorted - 1;
+  if (last < 0) { NN_UNPACK(best, bi, bd) return; }
+  // The search is latency-bound: 4 row headers (8 loads) are fetched together, then the first NVF
+  // candidates of all 4 rows together; only rows with more candidates take further round trips.
+  // Clamped duplicate loads are harmless (same key), out-of-range slots are masked.
   for (int cy = cy0; cy <= cy1; cy += 4) {
     int rb[4], re[4];
 #pragma unroll
@@ -491,17 +504,26 @@ __device__ __forceinline__ void nn_search_global(const IcpShared &S, const float
       rb[u] = cell_start[cyu * S.GX + cx0];             // cells of a row are contiguous
       re[u] = cell_start[cyu * S.GX + cx1 + 1];
     }
+    float4 p[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int b = rb[u], e = cy + u <= cy1 ? re[u] : rb[u];   // predicated, keeps rb/re in registers
-      for (int s = b; s < e; s += 4) {
-        float4 p[4];
+      if (cy + u > cy1) re[u] = rb[u];                  // predicated: keeps rb/re in registers
 #pragma unroll
-        for (int v = 0; v < 4; ++v) p[v] = sref[min(s + v, e - 1)];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) NN_CONSIDER(p[v])
-      }
+      for (int v = 0; v < 4; ++v) p[u][v] = sref[min(rb[u] + v, last)];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) NN_CONSIDER_IF(p[u][v], rb[u] + v < re[u])
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      for (int s = rb[u] + 4; s < re[u]; s += 4) {
+        float4 q[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) q[v] = sref[min(s + v, re[u] - 1)];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) NN_CONSIDER(q[v])
+      }
   }
   NN_UNPACK(best, bi, bd)
 }

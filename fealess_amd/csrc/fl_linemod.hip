@@ -171,6 +171,7 @@ struct ScanArgs {
   size_t lm_off[FL_MAX_MODALITIES];
   size_t off_count, off_cand;
   int n_pyr, M, nchunks, W, WH, T, cap;
+  int bpf, n_frames;         // blocks per frame, frames in this launch
   float threshold;
   uint16_t *dbg;             // optional raw u16 maps of pyramids [dbg_first, dbg_first+dbg_count)
   int dbg_first, dbg_count;
@@ -186,10 +187,16 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *p)
 __global__ __launch_bounds__(256) void k_scan(ScanArgs a)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+  // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs, each with its own
+  // 4 MB L2.  All blocks of one frame are given the same residue mod 8, so a frame's linear
+  // memories (1.2 MB at VGA level 1) are fetched into ONE L2 and reused by every template there,
+  // instead of being streamed into all eight.  Placement only affects speed, never results.
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int frame = xcd + 8 * (q / a.bpf);
+  if (frame >= a.n_frames) return;
+  const int item = __builtin_amdgcn_readfirstlane((q % a.bpf) * 4 + wave);
   if (item >= a.n_pyr * a.nchunks) return;
   const int g = item / a.nchunks, chunk = item - g * a.nchunks;
-  const int frame = blockIdx.y;
   uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
   const int j0 = chunk * 1024 + lane * 16;
 
@@ -493,7 +500,9 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.dbg_count = dbg_count;
     const int items = det->n_pyr * a.nchunks;
     if (items > 0) {
-      dim3 grid((items + 3) / 4, n_frames);
+      a.bpf = (items + 3) / 4;
+      a.n_frames = n_frames;
+      dim3 grid((unsigned)(a.bpf * ((n_frames + 7) / 8) * 8));
       hipLaunchKernelGGL(k_scan, grid, dim3(256), 0, ctx->stream, a);
       FL_HIP(ctx, hipGetLastError());
     }
