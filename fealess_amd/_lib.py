@@ -102,6 +102,7 @@ SIGNATURES = {
     "fl_export_topk": (_I, [_P, _I, _I, _I, _P]),
     "fl_merge_topk": (_I, [_P, _I, _P, _I]),
     "fl_last_stage_times": (_I, [_P, C.POINTER(StageTimes)]),
+    "fl_frame_counters": (_I, [_P, _I, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -528,7 +528,9 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.cap = det->cap;
     a.zero_off = g.zero_off;
     a.threshold = threshold;
-    dim3 grid(n_frames >= 64 ? 32 : 256, n_frames);
+    // few workgroups per frame: candidates are typically tens per frame and idle workgroups are not
+    // free (every wave still fetches the frame's counter); heavy frames just loop longer
+    dim3 grid(n_frames >= 64 ? 4 : (n_frames >= 8 ? 32 : 256), n_frames);
     hipLaunchKernelGGL(k_refine, grid, dim3(256), 0, ctx->stream, a);
     FL_HIP(ctx, hipGetLastError());
   }
@@ -649,6 +651,17 @@ extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16
   rc = launch_scan_refine_sort(det, 1, 200.0f, (uint16_t *)d, first, count);
   if (rc) return rc;
   FL_HIP(ctx, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FL_OK;
+}
+
+extern "C" int fl_frame_counters(fl_detector *det, int frame, int32_t out[4])
+{
+  if (!det || !out) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || frame < 0 || frame >= det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "frame");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  FL_HIP(ctx, hipMemcpyAsync(out, det->d_ws + (size_t)frame * det->ws_stride + det->off_count, 16, hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return FL_OK;
 }

@@ -208,6 +208,10 @@ int  fl_export_topk(fl_detector *det, int frame, int k, int template_id_base, vo
  * order them; returns the number written to out (<= cap). */
 int  fl_merge_topk(const fl_match *gathered, int n_records, fl_match *out, int cap);
 
+/* diagnostics: per-frame counters of the last match {coarse candidates, matches after sort/unique,
+ * overflow flag, 0} (host memory) */
+int  fl_frame_counters(fl_detector *det, int frame, int32_t out[4]);
+
 /* per-stage device time (ms) of the last fl_recognize_* call, by stage index; for bench.py */
 typedef struct {
   float frontend_ms, linmem_ms, scan_ms, refine_ms, sort_ms, backproject_ms, icp_ms, total_ms;
