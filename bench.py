@@ -192,17 +192,23 @@ def main():
     # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE, separate passes, same command); only quoted when the workload matches
     traffic = None
+    traffic_detail = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_b1024.json")))
         if pm["batch"] == B and pm["templates"] == bank.n_pyramids and args.icp_mode == "parity":
             kd = pm["kernels"][dom if dom != "k_icp_pipeline" else "k_icp_pipeline<0>"]
-            traffic = dict(fetch_bytes=kd["FETCH_SIZE"] * 1024, write_bytes=kd["WRITE_SIZE"] * 1024, unit="bytes/launch",
-                           note="raw rocprofv3 counters; gfx950 FETCH_SIZE under-counts wide coalesced reads by up to 2x")
+            traffic = (kd["FETCH_SIZE"] + kd["WRITE_SIZE"]) * 1024.0          # bytes per launch, raw counters
+            traffic_detail = dict(fetch_bytes=kd["FETCH_SIZE"] * 1024, write_bytes=kd["WRITE_SIZE"] * 1024,
+                                  source="profiles/r01_pmc_b1024.json",
+                                  note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; gfx950 FETCH_SIZE "
+                                       "under-counts wide coalesced reads by up to 2x (this kernel's reads are mostly "
+                                       "4-16 B gathers: uncalibrated), so true HBM reads lie between 1x and 2x fetch_bytes")
     except Exception:
         traffic = None
     roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic,
-                    launch_ms=round(kern[dom]["ms"], 4), algorithmic_bytes_per_launch=kern[dom]["bytes"])
+                    launch_ms=round(kern[dom]["ms"], 4), algorithmic_bytes_per_launch=kern[dom]["bytes"],
+                    traffic_detail=traffic_detail)
     scan_ach = scan_bytes / (times["scan_ms"] * 1e-3) / 1e9 if times["scan_ms"] > 0 else 0.0
 
     out = None
