@@ -354,7 +354,6 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
       }
       // finer levels: refinement tables (similarityLocal(), linemod.cpp:1226-1300)
       for (int l = 0; l < L - 1; ++l) {
-        const FlLevelGeom &g = det->geom[l];
         for (int m = 0; m < M; ++m) {
           const fl_template &t = tp[l * M + m];
           FlFineHdr h;
@@ -367,13 +366,16 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
             FlFineFeat ff;
             ff.x = (int16_t)f.x;
             ff.y = (int16_t)f.y;
-            // with offsets that are multiples of T, (f+off)%T == f%T and (f+off)/T == f/T + off/T
-            // whenever f+off >= 0 (tested on the device); negative f itself is always skipped when
-            // off <= 0 and handled by the bounds test otherwise -- store the residues of |f| safely:
-            int fx = f.x, fy = f.y;
-            int rx = ((fx % g.T) + g.T) % g.T, ry = ((fy % g.T) + g.T) % g.T;
-            int qx = (fx - rx) / g.T, qy = (fy - ry) / g.T;   // floor division
-            ff.lmoff = (uint32_t)((int64_t)f.label * g.stride + (int64_t)(ry * g.T + rx) * g.WH + (int64_t)qy * g.W + qx);
+            {
+              const int Tl = det->geom[l].T;
+              const int rx = ((f.x % Tl) + Tl) % Tl, ry = ((f.y % Tl) + Tl) % Tl;
+              ff.gx = (uint8_t)rx;
+              ff.gy = (uint8_t)ry;
+              ff.qx = (int16_t)((f.x - rx) / Tl);
+              ff.qy = (int16_t)((f.y - ry) / Tl);
+              ff.label = (uint8_t)f.label;
+              ff.pad = 0;
+            }
             fine_feat.push_back(ff);
           }
           fine_hdr.push_back(h);
@@ -407,7 +409,12 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
     FlLevelGeom &g = det->geom[l];
     g.bgr_off = l == 0 ? det->off_bgr : take((size_t)g.w * g.h * 3);
     for (int m = 0; m < M; ++m) g.quant_off[m] = take((size_t)g.w * g.h);
-    for (int m = 0; m < M; ++m) g.lm_off[m] = take((size_t)8 * g.stride + 64);
+    // only the coarsest level is scanned by every template and gets linear memories; the finer
+    // levels are touched by a handful of 16x16 patches per frame and keep just the spread image
+    for (int m = 0; m < M; ++m) {
+      g.lm_off[m] = l == L - 1 ? take((size_t)8 * g.stride + 64) : 0;
+      g.spread_off[m] = l == L - 1 ? 0 : take((size_t)g.w * g.h + 64);
+    }
   }
   det->off_tmp = take((size_t)w0 * h0);
   det->off_count = take(256);

@@ -47,9 +47,11 @@ struct FlScanHdr {       // one per (pyramid g, modality m) at the coarsest leve
   int32_t n_pad;         // entries, padded to a multiple of 8 with the zero offset
   int32_t nf;            // templ.features.size() (counts skipped features too)
 };
-struct FlFineFeat {      // one per feature at the finer levels
-  int16_t x, y;          // template-relative position (for the bounds test, linemod.cpp:1257)
-  uint32_t lmoff;        // label*stride + grid*WH + (y/T)*W + x/T
+struct FlFineFeat {      // one per feature at the finer levels (12 bytes)
+  int16_t x, y;          // template-relative position
+  int16_t qx, qy;        // floor(x / T), floor(y / T)
+  uint8_t gx, gy;        // x mod T, y mod T (non-negative): the grid cell, invariant under offsets that are multiples of T
+  uint8_t label, pad;    // quantized orientation 0..7
 };
 struct FlFineHdr {       // one per (pyramid g, level l < L-1, modality m)
   int32_t feat_begin, feat_count;
@@ -72,7 +74,8 @@ struct FlLevelGeom {
   uint32_t stride;       // bytes per label block
   uint32_t zero_off;     // offset (within a modality's LM) of >= WH+16W+64 zero bytes
   size_t quant_off[FL_MAX_MODALITIES];   // offsets inside a frame workspace
-  size_t lm_off[FL_MAX_MODALITIES];
+  size_t lm_off[FL_MAX_MODALITIES];      // coarsest level only: the 8 linear memories
+  size_t spread_off[FL_MAX_MODALITIES];  // finer levels: the spread image (w*h bytes)
   size_t bgr_off;                        // colour image of this level
 };
 
@@ -132,6 +135,8 @@ struct fl_detector {
 // linemod
 int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *lm,
                        size_t lm_stride, int n_frames, int w, int h, int T);
+int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread,
+                     size_t spread_stride, int n_frames, int w, int h, int T);
 int fl_launch_match_core(fl_detector *det, int n_frames, float threshold);
 // frontend
 int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t in_stride,

@@ -125,6 +125,85 @@ __global__ __launch_bounds__(256) void k_build_lm(const uint8_t *__restrict__ qu
   }
 }
 
+// k_spread: the spread image alone (linemod.cpp:950-965) for the finer pyramid levels, same LDS
+// separable OR as k_build_lm.  Those levels are only read by k_refine (a few 16x16 patches per
+// frame), which evaluates the response LUT on the fly instead of reading 8 linear memories.
+__global__ __launch_bounds__(256) void k_spread(const uint8_t *__restrict__ quant, size_t quant_stride,
+                                                uint8_t *__restrict__ spread, size_t spread_stride, int w, int h, int T, int RS)
+{
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int ws = w + 16, rows_in = RS + T - 1;
+  uint8_t *A = smem, *B = smem + (size_t)rows_in * ws;
+  const uint8_t *q = quant + (size_t)blockIdx.z * quant_stride;
+  uint8_t *out = spread + (size_t)blockIdx.z * spread_stride;
+  const int y0 = blockIdx.x * RS, tid = threadIdx.x;
+  const int ws4 = ws >> 2, w4 = w >> 2;
+  for (int i = tid; i < rows_in * ws4; i += 256) {
+    const int r = i / ws4, c4 = i - r * ws4;
+    const int y = y0 + r;
+    uint32_t v = 0;
+    if (y < h && c4 < w4) v = *(const uint32_t *)(q + (size_t)y * w + 4 * c4);
+    ((uint32_t *)A)[i] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < rows_in * w4; i += 256) {
+    const int r = i / w4, c4 = i - r * w4;
+    const uint32_t *src = (const uint32_t *)(A + (size_t)r * ws) + c4;
+    const unsigned long long lo = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
+    const unsigned long long hi = (unsigned long long)src[2] | ((unsigned long long)src[3] << 32);
+    unsigned long long acc = lo;
+    for (int c = 1; c < T; ++c) acc |= (lo >> (8 * c)) | (hi << (64 - 8 * c));
+    ((uint32_t *)(B + (size_t)r * ws))[c4] = (uint32_t)acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < RS * w4; i += 256) {
+    const int r = i / w4, c4 = i - r * w4;
+    if (y0 + r >= h) continue;
+    uint32_t acc = 0;
+    for (int rr = 0; rr < T; ++rr) acc |= ((const uint32_t *)(B + (size_t)(r + rr) * ws))[c4];
+    *(uint32_t *)(out + (size_t)(y0 + r) * w + 4 * c4) = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_spread_generic(const uint8_t *__restrict__ quant, size_t quant_stride,
+                                                        uint8_t *__restrict__ spread, size_t spread_stride, int w, int h, int T)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const uint8_t *q = quant + (size_t)blockIdx.z * quant_stride;
+  unsigned b = 0;
+  const int rmax = min(T, h - y), cmax = min(T, w - x);
+  for (int r = 0; r < rmax; ++r)
+    for (int c = 0; c < cmax; ++c) b |= q[(size_t)(y + r) * w + x + c];
+  spread[(size_t)blockIdx.z * spread_stride + (size_t)y * w + x] = (uint8_t)b;
+}
+
+int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread, size_t spread_stride,
+                     int n_frames, int w, int h, int T)
+{
+  const bool aligned = ((uintptr_t)quant % 4 == 0) && (quant_stride % 4 == 0) && ((uintptr_t)spread % 4 == 0) && (spread_stride % 4 == 0);
+  if (w % 4 == 0 && T <= 8 && T >= 2 && aligned) {
+    int k = 4;
+    size_t lds;
+    for (;;) {
+      lds = (size_t)2 * (k * T + T - 1) * (w + 16);
+      if (lds <= 60 * 1024 || k == 1) break;
+      --k;
+    }
+    if (lds <= 64 * 1024) {
+      const int RS = k * T;
+      dim3 grid((h + RS - 1) / RS, 1, n_frames);
+      hipLaunchKernelGGL(k_spread, grid, dim3(256), lds, ctx->stream, quant, quant_stride, spread, spread_stride, w, h, T, RS);
+      FL_HIP(ctx, hipGetLastError());
+      return FL_OK;
+    }
+  }
+  dim3 grid((w + 63) / 64, (h + 3) / 4, n_frames);
+  hipLaunchKernelGGL(k_spread_generic, grid, dim3(256), 0, ctx->stream, quant, quant_stride, spread, spread_stride, w, h, T);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
 int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *lm,
                        size_t lm_stride, int n_frames, int w, int h, int T)
 {
@@ -262,15 +341,38 @@ __global__ __launch_bounds__(256) void k_scan(ScanArgs a)
 // ------------------------------------------------------------------------------------------
 // k_refine: one wavefront per candidate.  The 16x16 patch is held as 64 lanes x 4 packed bytes
 // (lane = row*4 + column group); each in-bounds feature costs one 4-byte load per lane.
+// Slow path of k_refine: 4 consecutive linear-memory positions that run past a row end (xt >= W) or
+// past the memory (yt >= H -> next grid cell; past the last one: 0), mapped back to spread pixels.
+// Returns the 4 spread bytes packed.
+__device__ __noinline__ uint32_t refine_slow_path(const uint8_t *sp, bool in, int xt0, int yt0, int gx, int gy, int T,
+                                                  int W, int H, int w)
+{
+  uint32_t out = 0;
+  const int g0 = gy * T + gx, TT = T * T;
+  for (int c = 0; c < 4; ++c) {
+    int xx = xt0 + c, yy = yt0, gg = g0;
+    const int wx = xx >= W ? xx / W : 0;
+    xx -= wx * W;
+    yy += wx;
+    const int wy = yy >= H ? yy / H : 0;
+    yy -= wy * H;
+    gg += wy;
+    if (in && gg < TT) {
+      const int ggy = gg / T, ggx = gg - ggy * T;
+      out |= (uint32_t)sp[(size_t)(yy * T + ggy) * w + (size_t)(xx * T + ggx)] << (8 * c);
+    }
+  }
+  return out;
+}
+
 struct RefineArgs {
   const FlFineHdr *hdr;
   const FlFineFeat *feat;
   uint8_t *ws;
   size_t ws_stride;
-  size_t lm_off[FL_MAX_MODALITIES];
+  size_t spread_off[FL_MAX_MODALITIES];
   size_t off_count, off_cand;
-  int M, Lm1, level, w, h, T, W, cap;
-  uint32_t zero_off;         // offset of the zero pad inside a modality's linear memories
+  int M, Lm1, level, w, h, T, W, H, cap;
   float threshold;
 };
 
@@ -284,7 +386,14 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
   const int row = lane >> 2, col4 = (lane & 3) * 4;
   const int T = a.T, W = a.W;
   const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
+#ifdef FL_REFINE_DEBUG
+  long long t_start = clock64();
+  int n_done = 0;
+#endif
   for (int ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
+#ifdef FL_REFINE_DEBUG
+    ++n_done;
+#endif
     FlCand cd = cand[ci];
     const int g = __builtin_amdgcn_readfirstlane(cd.g);
     if (g < 0) continue;
@@ -297,30 +406,71 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
     x = min(x, max_x);
     y = min(y, max_y);
     const int offset_x = (x / T - 8) * T, offset_y = (y / T - 8) * T;   // C division (trunc), :1240
-    const int shift = (offset_y / T) * W + offset_x / T;
     uint32_t tot0 = 0, tot1 = 0, tot2 = 0, tot3 = 0;                    // u16 totals of 4 positions
     int numFeatures = 0;
+    const int H = a.H;
+    const int offx_t = offset_x / T, offy_t = offset_y / T;
+    const size_t lane_off = (size_t)row * T * a.w + (size_t)col4 * T;
     for (int m = 0; m < a.M; ++m) {
       const FlFineHdr h = hdr[m];
       numFeatures += h.feat_count;
-      const uint8_t *lm = ws + a.lm_off[m] + row * W + col4;
+      const uint8_t *sp = ws + a.spread_off[m];
       const FlFineFeat *ff = a.feat + h.feat_begin;
       uint32_t acc = 0;
-      // 8 features per step, branch-free: a feature that leaves the image (:1257) reads the zero
-      // pad instead, so the 8 loads are independent and in flight together
+      // The reference reads 16 rows x 16 bytes of the feature's linear memory at stride W starting at
+      // lm_index (:1260-1297).  Here the same linear index is mapped back to the pixel it was
+      // linearised from -- grid cell g, position k = yt*W + xt -> (yt*T + g/T, xt*T + g%T) -- and the
+      // response LUT is evaluated on the spread byte.  Running past a row (xt >= W) or past the
+      // memory (yt >= H -> next grid cell, past the last one: 0) follows the linear layout exactly.
+      // lane l holds feature l of this template (<= 63 features <= 64 lanes): one coalesced 12-byte
+      // load per lane, after which every feature is broadcast from registers -- no per-feature
+      // memory round trip.  Then 8 features x 4 positions = 32 independent byte loads per step.
+      int f_xy = 0, f_q = 0, f_g = 0;
+      if (lane < h.feat_count) {
+        const FlFineFeat f = ff[lane];
+        f_xy = (int)(uint16_t)f.x | ((int)(uint16_t)f.y << 16);
+        f_q = (int)(uint16_t)f.qx | ((int)(uint16_t)f.qy << 16);
+        f_g = (int)f.gx | ((int)f.gy << 8) | ((int)f.label << 16);
+      }
       for (int k = 0; k < h.feat_count; k += 8) {
-        uint32_t off[8], v[8];
+        uint32_t b[8][4];
+        int lab[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const FlFineFeat f = ff[min(k + u, h.feat_count - 1)];
-          const int fx = f.x + offset_x, fy = f.y + offset_y;
-          const bool in = (k + u < h.feat_count) && fx >= 0 && fy >= 0 && fx < a.w && fy < a.h;
-          off[u] = in ? (uint32_t)(f.lmoff + (uint32_t)shift) : a.zero_off;
+          const int idx = min(k + u, h.feat_count - 1);                    // wave-uniform
+          const int xy = __shfl(f_xy, idx, 64), qq = __shfl(f_q, idx, 64), gl = __shfl(f_g, idx, 64);
+          const int fx = (int)(int16_t)(xy & 0xFFFF) + offset_x, fy = (int)(int16_t)(xy >> 16) + offset_y;
+          const bool in = (k + u < h.feat_count) && fx >= 0 && fy >= 0 && fx < a.w && fy < a.h;   // :1257
+          lab[u] = (gl >> 16) & 0xFF;
+          // offsets are multiples of T, so (f + offset) mod T and div T follow from the stored residues
+          const int gx = gl & 0xFF, gy = (gl >> 8) & 0xFF;
+          const int lm_x = (int)(int16_t)(qq & 0xFFFF) + offx_t, lm_y = (int)(int16_t)(qq >> 16) + offy_t;
+          if (in && lm_x + 15 < W && lm_y + 15 < H) {                      // wave-uniform: the usual case
+            // the 16x16 patch stays inside its linear memory: position (row, col4 + c) is simply the
+            // pixel (fy + row*T, fx + (col4 + c)*T)
+            const uint8_t *p0 = sp + (size_t)(fy * a.w + fx) + lane_off;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[u][c] = p0[c * T];
+          } else {
+            // rare: the patch leaves its linear memory (or the feature is out of the image); kept out
+            // of line so the unrolled step stays small (instruction-cache footprint)
+            uint32_t r4 = refine_slow_path(sp, in, lm_x + col4, lm_y + row, gx, gy, T, W, H, a.w);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[u][c] = (r4 >> (8 * c)) & 0xFFu;
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) __builtin_memcpy(&v[u], lm + off[u], 4);
+        for (int u = 0; u < 8; ++u) {
+          uint32_t packed = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];                          // 4 packed u8 adds each
+          for (int c = 0; c < 4; ++c) {
+            const unsigned bb = b[u][c] | (b[u][c] << 8);
+            const unsigned rot = (bb >> lab[u]) & 0xFFu;
+            const unsigned r = (rot & 1u) ? 4u : ((rot & 0x82u) ? 2u : ((rot & 0x44u) ? 1u : 0u));
+            packed |= r << (8 * c);
+          }
+          acc += packed;                                                   // 4 packed u8 adds
+        }
       }
       tot0 += acc & 0xFFu;
       tot1 += (acc >> 8) & 0xFFu;
@@ -350,6 +500,9 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
       cand[ci] = cd;
     }
   }
+#ifdef FL_REFINE_DEBUG
+  if (blockIdx.y == 0 && lane == 0) printf("refine dbg: block %d wave %d n %d done %d cycles %lld\n", blockIdx.x, wave, n, n_done, clock64() - t_start);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -515,7 +668,7 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.feat = det->d_fine_feat;
     a.ws = det->d_ws;
     a.ws_stride = det->ws_stride;
-    for (int m = 0; m < FL_MAX_MODALITIES; ++m) a.lm_off[m] = g.lm_off[m < M ? m : 0];
+    for (int m = 0; m < FL_MAX_MODALITIES; ++m) a.spread_off[m] = g.spread_off[m < M ? m : 0];
     a.off_count = det->off_count;
     a.off_cand = det->off_cand;
     a.M = M;
@@ -525,8 +678,8 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.h = g.h;
     a.T = g.T;
     a.W = g.W;
+    a.H = g.H;
     a.cap = det->cap;
-    a.zero_off = g.zero_off;
     a.threshold = threshold;
     // few workgroups per frame: candidates are typically tens per frame and idle workgroups are not
     // free (every wave still fetches the frame's counter); heavy frames just loop longer
@@ -561,8 +714,11 @@ int fl_launch_match_core(fl_detector *det, int n_frames, float threshold)
   for (int l = 0; l < det->L; ++l) {
     const FlLevelGeom &g = det->geom[l];
     for (int m = 0; m < det->M; ++m) {
-      int rc = fl_launch_build_lm(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.lm_off[m],
-                                  det->ws_stride, n_frames, g.w, g.h, g.T);
+      int rc = l == det->L - 1
+                   ? fl_launch_build_lm(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.lm_off[m],
+                                        det->ws_stride, n_frames, g.w, g.h, g.T)
+                   : fl_launch_spread(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.spread_off[m],
+                                      det->ws_stride, n_frames, g.w, g.h, g.T);
       if (rc) return rc;
     }
   }
