@@ -174,13 +174,20 @@ class Detector:
         self.ctx.check(self.lib.fl_match_quantized(self.h, ptrs, L.FL_MEM_HOST, threshold, _ptr(out), cap, C.byref(n)))
         return out[:min(n.value, cap)], n.value
 
-    def match(self, bgr, depth, threshold, cap=65536):
+    def match(self, bgr, depth, threshold, cap=65536, masks=None):
+        """Detector::match (linemod.hpp:319-327); masks: None or one u8 image (or None) per modality."""
         bgr = np.ascontiguousarray(bgr, np.uint8)
         depth = np.ascontiguousarray(depth, np.uint16) if depth is not None else None
         out = np.zeros(cap, MATCH_DTYPE)
         n = C.c_int(0)
-        self.ctx.check(self.lib.fl_match_frame(self.h, _ptr(bgr), _ptr(depth) if depth is not None else None,
-                                               L.FL_MEM_HOST, threshold, _ptr(out), cap, C.byref(n)))
+        mp = None
+        if masks is not None:
+            if len(masks) != self.M:
+                raise FealessError(L.FL_ERR_INVALID, "masks.size() != modalities.size() (linemod.cpp:1365)")
+            mk = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in masks]
+            mp = (C.c_void_p * self.M)(*[None if m is None else m.ctypes.data for m in mk])
+        self.ctx.check(self.lib.fl_match_frame_masked(self.h, _ptr(bgr), _ptr(depth) if depth is not None else None, mp,
+                                                      L.FL_MEM_HOST, threshold, _ptr(out), cap, C.byref(n)))
         return out[:min(n.value, cap)], n.value
 
     def similarity_maps(self, first, count):

@@ -764,8 +764,27 @@ extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quanti
   return read_matches(det, 0, out, cap, n_total);
 }
 
-extern "C" int fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, float threshold,
-                        fl_match *out, int cap, int *n_total)
+// QuantizedPyramid::quantize with a mask (`angle.copyTo(dst, mask)` linemod.cpp:455-459, `normal.copyTo(dst, mask)`
+// :741-745): level l keeps a pixel only where the l-times NN-halved mask (:445-450, :733-738) is non-zero.  The chain of
+// cv::resize(INTER_NEAREST) source coordinates is composed here so the mask pyramid is never materialised.
+__global__ __launch_bounds__(256) void k_apply_mask(uint8_t *__restrict__ quant, const uint8_t *__restrict__ mask, int w0,
+                                                    int h0, int level)
+{
+  const int w = w0 >> level, h = h0 >> level;
+  int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const size_t o = (size_t)y * w + x;
+  for (int k = level; k >= 1; --k) {
+    const int sw = w0 >> (k - 1), sh = h0 >> (k - 1), dw = sw / 2, dh = sh / 2;
+    x = min((int)floor(x * (1.0 / ((double)dw / sw))), sw - 1);
+    y = min((int)floor(y * (1.0 / ((double)dh / sh))), sh - 1);
+  }
+  if (!mask[(size_t)y * w0 + x]) quant[o] = 0;
+}
+
+extern "C" int fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
+                                     const uint8_t *const *masks, int mem, float threshold, fl_match *out, int cap,
+                                     int *n_total)
 {
   if (!det || !bgr || cap < 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
@@ -773,18 +792,50 @@ extern "C" int fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16
   if (det->M == 2 && !depth) return fl_set_error(ctx, FL_ERR_INVALID, "sources.size() != modalities.size() (linemod.cpp:1364)");
   FL_HIP(ctx, hipSetDevice(ctx->device));
   const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_bgr, bgr, (size_t)det->w0 * det->h0 * 3, kind, ctx->stream));
-  if (det->M == 2)
-    FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_depth, depth, (size_t)det->w0 * det->h0 * 2, kind, ctx->stream));
+  const size_t px = (size_t)det->w0 * det->h0;
+  FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_bgr, bgr, px * 3, kind, ctx->stream));
+  if (det->M == 2) FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_depth, depth, px * 2, kind, ctx->stream));
   det->have_times = false;
   int rc = fl_launch_frontend(det, 1, det->d_ws + det->off_bgr, det->ws_stride,
                               (const uint16_t *)(det->d_ws + det->off_depth), det->ws_stride);
   if (rc) return rc;
-  rc = fl_launch_match_core(det, 1, threshold);
-  if (rc) return rc;
-  det->last_batch = 1;
-  det->last_from_images = true;
-  return read_matches(det, 0, out, cap, n_total);
+  uint8_t *d_mask = nullptr;
+  if (masks) {
+    if (mem != FL_MEM_DEVICE) FL_HIP(ctx, hipMalloc(&d_mask, px * det->M));
+    for (int m = 0; m < det->M && rc == FL_OK; ++m) {
+      if (!masks[m]) continue;
+      const uint8_t *dm = masks[m];
+      if (mem != FL_MEM_DEVICE) {
+        dm = d_mask + px * m;
+        if (hipMemcpyAsync((void *)dm, masks[m], px, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = FL_ERR_HIP;
+      }
+      for (int l = 0; l < det->L && rc == FL_OK; ++l) {
+        const FlLevelGeom &g = det->geom[l];
+        hipLaunchKernelGGL(k_apply_mask, dim3((g.w + 63) / 64, (g.h + 3) / 4), dim3(256), 0, ctx->stream,
+                           det->d_ws + g.quant_off[m], dm, det->w0, det->h0, l);
+        if (hipGetLastError() != hipSuccess) rc = FL_ERR_HIP;
+      }
+    }
+  }
+  if (rc == FL_OK) rc = fl_launch_match_core(det, 1, threshold);
+  if (rc == FL_OK) {
+    det->last_batch = 1;
+    det->last_from_images = true;
+    rc = read_matches(det, 0, out, cap, n_total);
+  } else if (rc == FL_ERR_HIP) {
+    fl_set_error(ctx, rc, "mask upload / k_apply_mask launch failed");
+  }
+  if (d_mask) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_mask);
+  }
+  return rc;
+}
+
+extern "C" int fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, float threshold,
+                        fl_match *out, int cap, int *n_total)
+{
+  return fl_match_frame_masked(det, bgr, depth, nullptr, mem, threshold, out, cap, n_total);
 }
 
 extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16_t *out)

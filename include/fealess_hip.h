@@ -176,6 +176,13 @@ int  fl_match_quantized(fl_detector *det, const uint8_t *const *quantized, int m
 /* From a BGR8 + depth16 frame with the default modality parameters (linemod.cpp:515-519,827-832) */
 int  fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem,
               float threshold, fl_match *out, int cap, int *n_total);
+/* Detector::match's optional `masks` argument (linemod.hpp:319-327, linemod.cpp:1364-1379): masks is
+ * NULL (empty vector) or an array of `modalities` pointers to w0*h0 u8 images in `mem`, each of
+ * which may be NULL (empty Mat).  A level-l pixel is kept where the l-times NN-halved mask is
+ * non-zero (linemod.cpp:445-459, 733-745). */
+int  fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
+                           const uint8_t *const *masks, int mem, float threshold, fl_match *out,
+                           int cap, int *n_total);
 /* similarity + addSimilarities (linemod.cpp:1130-1214,1322-1338) for pyramids [first,first+count)
  * at the coarsest level of the frame last passed to fl_match_*: out = count * (W_T*H_T) u16 (host) */
 int  fl_similarity_maps(fl_detector *det, int first, int count, uint16_t *out);

@@ -98,6 +98,13 @@ int  orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
                       const orc_bank *banks, int n_classes, float threshold,
                       orc_match *out, int cap, int *n_total, uint8_t *quantized_out);
 
+/* same with the optional per-modality masks of Detector::match (linemod.hpp:319-327); NULL = empty */
+int  orc_match_images_masked(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
+                             int levels, const int *T_at_level,
+                             const orc_bank *banks, int n_classes, float threshold,
+                             const uint8_t *mask_color, const uint8_t *mask_depth,
+                             orc_match *out, int cap, int *n_total, uint8_t *quantized_out);
+
 /* ---- back-projection + ICP ------------------------------------------------------------- */
 /* cup_d2pc::depthTo3d u16 path (depth_to_3d.cpp:99-137,190-221,244-269): out is w*h*3 f32, metres */
 void orc_depth_to_3d(const uint16_t *depth, int w, int h, double fx, double fy, double cx,

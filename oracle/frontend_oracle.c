@@ -277,16 +277,26 @@ void orc_quantized_normals(const uint16_t *depth, int w, int h, int distance_thr
 }
 
 /* Detector::match from images: ColorGradientPyramid + DepthNormalPyramid quantizers
- * (linemod.cpp:416-459, 710-745) feeding orc_match_quantized. */
-int orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
-                     int levels, const int *T_at_level,
-                     const orc_bank *banks, int n_classes, float threshold,
-                     orc_match *out, int cap, int *n_total, uint8_t *quantized_out)
+ * (linemod.cpp:416-459, 710-745) feeding orc_match_quantized.  masks (optional, one per modality,
+ * each may be NULL = empty Mat): quantize() keeps a pixel only where the mask is non-zero
+ * (`angle.copyTo(dst, mask)`, :455-459, :741-745); the mask pyramid is NN-downsampled by 2 per level
+ * (:445-450, :733-738); the un-masked normal image is what gets downsampled (:731). */
+int orc_match_images_masked(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
+                            int levels, const int *T_at_level,
+                            const orc_bank *banks, int n_classes, float threshold,
+                            const uint8_t *mask_color, const uint8_t *mask_depth,
+                            orc_match *out, int cap, int *n_total, uint8_t *quantized_out)
 {
   const int M = 2;
-  uint8_t *q[32];
+  uint8_t *q[32] = {0};
   uint8_t *src = (uint8_t *)malloc((size_t)w0 * h0 * 3);
   memcpy(src, bgr, (size_t)w0 * h0 * 3);
+  uint8_t *normal = (uint8_t *)malloc((size_t)w0 * h0);
+  uint8_t *mk[2] = {NULL, NULL};
+  const uint8_t *mk_in[2] = {mask_color, mask_depth};
+  for (int m = 0; m < 2; ++m)
+    if (mk_in[m]) { mk[m] = (uint8_t *)malloc((size_t)w0 * h0); memcpy(mk[m], mk_in[m], (size_t)w0 * h0); }
+  orc_quantized_normals(depth, w0, h0, 2000, 50, normal);             /* DepthNormal() :827-832 */
   int w = w0, h = h0;
   for (int l = 0; l < levels; ++l) {
     if (l > 0) {
@@ -294,18 +304,33 @@ int orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
       orc_pyrdown_bgr(src, w, h, next);
       free(src);
       src = next;
-      q[l * M + 1] = (uint8_t *)malloc((size_t)(w / 2) * (h / 2));
-      orc_resize_nn_half(q[(l - 1) * M + 1], w, h, q[l * M + 1]);
+      uint8_t *nn = (uint8_t *)malloc((size_t)(w / 2) * (h / 2));
+      orc_resize_nn_half(normal, w, h, nn);
+      free(normal);
+      normal = nn;
+      for (int m = 0; m < 2; ++m)
+        if (mk[m]) {
+          uint8_t *nm = (uint8_t *)malloc((size_t)(w / 2) * (h / 2));
+          orc_resize_nn_half(mk[m], w, h, nm);
+          free(mk[m]);
+          mk[m] = nm;
+        }
       w /= 2;
       h /= 2;
-    } else {
-      q[1] = (uint8_t *)malloc((size_t)w * h);
-      orc_quantized_normals(depth, w, h, 2000, 50, q[1]);             /* DepthNormal() :827-832 */
     }
     q[l * M] = (uint8_t *)malloc((size_t)w * h);
     orc_quantized_orientations(src, w, h, 10.0f, q[l * M], NULL);     /* ColorGradient() :515-519 */
+    q[l * M + 1] = (uint8_t *)malloc((size_t)w * h);
+    memcpy(q[l * M + 1], normal, (size_t)w * h);
+    for (int m = 0; m < 2; ++m)
+      if (mk[m])
+        for (size_t i = 0; i < (size_t)w * h; ++i)
+          if (!mk[m][i]) q[l * M + m][i] = 0;
   }
   free(src);
+  free(normal);
+  free(mk[0]);
+  free(mk[1]);
   if (quantized_out) {
     uint8_t *o = quantized_out;
     for (int l = 0; l < levels; ++l)
@@ -319,4 +344,13 @@ int orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
                                n_classes, threshold, out, cap, n_total);
   for (int i = 0; i < levels * M; ++i) free(q[i]);
   return rc;
+}
+
+int orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
+                     int levels, const int *T_at_level,
+                     const orc_bank *banks, int n_classes, float threshold,
+                     orc_match *out, int cap, int *n_total, uint8_t *quantized_out)
+{
+  return orc_match_images_masked(bgr, depth, w0, h0, levels, T_at_level, banks, n_classes, threshold, NULL, NULL, out, cap,
+                                 n_total, quantized_out);
 }

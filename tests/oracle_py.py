@@ -183,7 +183,7 @@ def quantize_pyramid(bgr, depth, levels):
     return out
 
 
-def match_images(bgr, depth, T_pyramid, banks, threshold, cap=1 << 20):
+def match_images(bgr, depth, T_pyramid, banks, threshold, cap=1 << 20, masks=None):
     b = np.ascontiguousarray(bgr, np.uint8)
     d = np.ascontiguousarray(depth, np.uint16)
     h, w = d.shape
@@ -192,8 +192,12 @@ def match_images(bgr, depth, T_pyramid, banks, threshold, cap=1 << 20):
     arr, keep = _banks(banks)
     out = np.zeros(cap, MATCH_DTYPE)
     nt = C.c_int(0)
-    n = lib().orc_match_images(_p(b), _p(d), w, h, levels, T, arr, len(banks), C.c_float(threshold), _p(out), cap,
-                               C.byref(nt), None)
+    mks = [None, None]
+    if masks is not None:
+        mks = [None if m is None else np.ascontiguousarray(m, np.uint8) for m in masks]
+    n = lib().orc_match_images_masked(_p(b), _p(d), w, h, levels, T, arr, len(banks), C.c_float(threshold),
+                                      None if mks[0] is None else _p(mks[0]), None if mks[1] is None else _p(mks[1]),
+                                      _p(out), cap, C.byref(nt), None)
     if n < 0:
         raise AssertionError("reference CV_Assert")
     return out[:n], nt.value

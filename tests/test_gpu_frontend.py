@@ -76,3 +76,35 @@ def test_match_from_images_bit_exact(ctx, oracle, levels, T):
         assert np.array_equal(got[k], exp[k])
     assert np.array_equal(got["similarity"].view(np.uint32), exp["similarity"].view(np.uint32))
     det.close()
+
+
+@pytest.mark.parametrize("which", ["both", "color_only", "depth_only", "empty"])
+def test_match_with_masks_bit_exact(ctx, oracle, which):
+    """Detector::match's masks argument (linemod.cpp:445-459, 733-745, 1364-1379)."""
+    T, thr = [5, 8], 30.0
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=5, n_views=4, n_random=20)
+    rng = np.random.default_rng(11)
+    mc = (rng.random((480, 640)) < 0.5).astype(np.uint8) * 255       # speckled: exercises the NN mask pyramid
+    md = np.zeros((480, 640), np.uint8)
+    md[40:440, 101:345] = 7                                          # any non-zero value counts; cuts the object
+    masks = {"both": [mc, md], "color_only": [mc, None], "depth_only": [None, md], "empty": [None, None]}[which]
+    det = api.Detector(ctx, 2, T)
+    det.add_class(sc["bank"])
+    det.finalize(640, 480)
+    got, n_got = det.match(sc["bgr"], sc["depth"], thr, masks=masks)
+    exp, n_exp = oracle.match_images(sc["bgr"], sc["depth"], T, [sc["bank"]], thr, masks=masks)
+    plain, n_plain = oracle.match_images(sc["bgr"], sc["depth"], T, [sc["bank"]], thr)
+    assert n_got == n_exp and n_exp > 0
+    if which == "empty":
+        assert np.array_equal(exp, plain)
+    else:
+        assert not np.array_equal(exp[:1], plain[:1])                # the mask changed the outcome
+    for k in ("x", "y", "class_idx", "template_id"):
+        assert np.array_equal(got[k], exp[k])
+    assert np.array_equal(got["similarity"].view(np.uint32), exp["similarity"].view(np.uint32))
+    q = det.last_quantized()
+    if which in ("both", "depth_only"):
+        assert not q[1][:40].any() and not q[3][:20].any() and q[1][40:440, 101:345].any()
+    with pytest.raises(api.FealessError):
+        det.match(sc["bgr"], sc["depth"], thr, masks=[mc])           # masks.size() != modalities.size()
+    det.close()

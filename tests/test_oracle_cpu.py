@@ -279,3 +279,29 @@ def test_golden_frontend_icp_recognition(oracle):
     r = oracle.recognition(g["bgr"], g["depth"], tuple(g["K"]), [5, 8], bank, 75.0, 10, 0.5, 0.01)
     assert r["found"] == 1 and np.array_equal(r["pose"], g["pose"])
     assert [r["best"]["x"], r["best"]["y"], r["best"]["template_id"]] == g["best"].tolist()
+
+
+def test_masked_match_semantics(oracle):
+    """masks (linemod.cpp:445-459, 733-745): equal to matching the pyramid whose level-l image is zeroed where the
+    l-times NN-halved mask is zero; all-ones masks change nothing; an all-zero mask removes every match."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=5, n_views=3,
+                                 n_random=5, w=320, h=240)
+    T = [5, 8]
+    bank = [sc["bank"]]
+    plain, n_plain = oracle.match_images(sc["bgr"], sc["depth"], T, bank, 60.0)
+    ones = np.ones((240, 320), np.uint8)
+    same, n_same = oracle.match_images(sc["bgr"], sc["depth"], T, bank, 60.0, masks=[ones, ones])
+    assert n_plain > 0 and n_same == n_plain and np.array_equal(same, plain)
+    none, n_none = oracle.match_images(sc["bgr"], sc["depth"], T, bank, 60.0, masks=[ones * 0, ones * 0])
+    assert n_none == 0
+    rng = np.random.default_rng(3)
+    mc = (rng.random((240, 320)) < 0.8).astype(np.uint8)
+    md = (rng.random((240, 320)) < 0.8).astype(np.uint8) * 200
+    got, n_got = oracle.match_images(sc["bgr"], sc["depth"], T, bank, 60.0, masks=[mc, md])
+    q = oracle.quantize_pyramid(sc["bgr"], sc["depth"], 2)
+    q[0] = q[0] * (mc != 0)
+    q[1] = q[1] * (md != 0)
+    q[2] = q[2] * (mc[::2, ::2] != 0)
+    q[3] = q[3] * (md[::2, ::2] != 0)
+    exp, n_exp = oracle.match_quantized(q, 320, 240, T, bank, 60.0)
+    assert n_got == n_exp and np.array_equal(got, exp)
