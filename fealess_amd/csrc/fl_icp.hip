@@ -39,10 +39,11 @@
 //   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
 //   mod   n x 3 f32   model cloud, transformed in place every iteration
 //   sref  n x float4  reference cloud sorted by grid cell, w = original index (bit pattern)
-//   nn     n x i32    nearest reference index j of model point i found last (kept pair: j, dropped: ~j)
+//   nn     n x i32    nearest reference index j of model point i (kept pair: j, dropped: -1)
+//   bnd    n x f32    upper bound on the distance from model point i to its nearest reference point
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid
 struct IcpWsLayout {
-  size_t ref, mod, sref, nn, cell_start, cell_cur, total;
+  size_t ref, mod, sref, nn, bnd, cell_start, cell_cur, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -55,6 +56,7 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.mod = o; o = al256(o + 12 * nn);
   L.sref = o; o = al256(o + 16 * nn);
   L.nn = o; o = al256(o + 4 * nn);
+  L.bnd = o; o = al256(o + 4 * nn);
   L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
   L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
   L.total = o;
@@ -114,6 +116,8 @@ struct IcpShared {
 #ifdef FL_ICP_DEBUG
   int dbg[8];
   long long tacc[8], tlast;
+  long long ta1[24];
+  int cells_it[24], wmax_it[24];
 #endif
 };
 
@@ -434,16 +438,44 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
 }
 
 // ---- exact 1-NN within squared distance thr (float compare as the reference's `dists <= dist_thr`)
-// cell ranges a query has to visit; false if the query cannot have a neighbour at all
-// `bound` (>= the true nearest squared distance, e.g. the distance to last iteration's partner) only
-// shrinks the visited area: every point within sqrt(bound) is still seen, so the result is exact.
-__device__ __forceinline__ bool nn_ranges(const IcpShared &S, float qx, float qy, float qz, float thr, float bound, int *cx0,
-                                          int *cx1, int *cy0, int *cy1)
+// cell ranges a query has to visit; false if the query cannot have a neighbour at all.
+// `bnd` is an upper bound on the distance to SOME reference point (last iteration's partner plus how far the
+// query moved since, see l2dist_phase): it only shrinks the visited area -- every point within that distance
+// is still seen, so the result is the exact nearest neighbour.  r_thr = sqrtf(thr).
+// uniform base + 32-bit unsigned byte offset: one VGPR per address (global_load ... v_off, s[base]) instead of a
+// sign-extended 64-bit pointer pair -- the search keeps 24 addresses in flight
+template <typename T>
+__device__ __forceinline__ T ld_u32(const T *__restrict__ base, int idx)
+{
+  return *(const T *)((const char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
+}
+
+// the grid parameters as wave-uniform scalars (SGPRs): read from LDS they would each cost a VGPR in the search loop
+struct NnGrid {
+  float xmin, ymin, inv_c;
+  int GX, GY, nsorted;
+};
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ NnGrid nn_grid(const IcpShared &S)
+{
+  NnGrid g;
+  g.xmin = uniform_f(S.xmin);
+  g.ymin = uniform_f(S.ymin);
+  g.inv_c = uniform_f(S.inv_c);
+  g.GX = __builtin_amdgcn_readfirstlane(S.GX);
+  g.GY = __builtin_amdgcn_readfirstlane(S.GY);
+  g.nsorted = __builtin_amdgcn_readfirstlane(S.nsorted);
+  return g;
+}
+
+__device__ __forceinline__ bool nn_ranges(const NnGrid &S, float qx, float qy, float qz, float thr, float r_thr, float bnd,
+                                          int *cx0, int *cx1, int *cy0, int *cy1)
 {
   if (!(thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
-  // conservative search radius: float rounding of d2 and of the differences is far below the margin
-  const float lim = bound < thr ? bound : thr;           // NaN bound -> thr
-  const float r = isfinite(lim) ? sqrtf(lim) * 1.0001f + 1e-3f : INFINITY;
+  const float lim = fminf(bnd, r_thr);                   // NaN bnd -> r_thr
+  // conservative radius: float rounding of d2, of the coordinate differences and of the bound's own
+  // arithmetic is orders of magnitude below the relative margins
+  const float r = lim * 1.0001f + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) + 1e-30f;
   *cx0 = 0; *cx1 = S.GX - 1; *cy0 = 0; *cy1 = S.GY - 1;
   if (isfinite(r)) {
     *cx0 = cell_of(qx - r, S.xmin, S.inv_c, S.GX);
@@ -486,44 +518,45 @@ __device__ __forceinline__ bool nn_ranges(const IcpShared &S, float qx, float qy
   }
 
 // search of the cell rows [cy0, cy1] x [cx0, cx1]; the grid and the sorted cloud are L2-resident
-__device__ __forceinline__ void nn_search_global(const IcpShared &S, const float4 *__restrict__ sref,
+__device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *__restrict__ sref,
                                                  const int *__restrict__ cell_start, float qx, float qy, float qz, int cx0,
                                                  int cx1, int cy0, int cy1, int *bi, float *bd)
 {
   unsigned long long best = NN_KEY_NONE;
   const int last = S.nsorted - 1;
   if (last < 0) { NN_UNPACK(best, bi, bd) return; }
-  // The search is latency-bound: 4 row headers (8 loads) are fetched together, then the first NVF
-  // candidates of all 4 rows together; only rows with more candidates take further round trips.
-  // Clamped duplicate loads are harmless (same key), out-of-range slots are masked.
+  // The search is latency-bound and a wave pays for its slowest lane, so round trips are what counts:
+  // the headers of 4 grid rows (8 loads) are fetched together, then the candidates of all 4 row segments
+  // are enumerated as ONE flat list, 16 per round trip -- a lane needs ceil(total / 16) rounds however the
+  // candidates are spread over the rows.  Out-of-range slots are masked, their (clamped) loads harmless.
   for (int cy = cy0; cy <= cy1; cy += 4) {
     int rb[4], re[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int cyu = min(cy + u, cy1);
-      rb[u] = cell_start[cyu * S.GX + cx0];             // cells of a row are contiguous
-      re[u] = cell_start[cyu * S.GX + cx1 + 1];
+      rb[u] = ld_u32(cell_start, cyu * S.GX + cx0);      // cells of a row are contiguous
+      re[u] = ld_u32(cell_start, cyu * S.GX + cx1 + 1);
     }
-    float4 p[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 1; u < 4; ++u)
       if (cy + u > cy1) re[u] = rb[u];                  // predicated: keeps rb/re in registers
+    // flat index k -> slot k + adj[u] for pre[u] <= k < pre[u + 1]
+    const int pre1 = re[0] - rb[0], pre2 = pre1 + (re[1] - rb[1]), pre3 = pre2 + (re[2] - rb[2]);
+    const int tot = pre3 + (re[3] - rb[3]);
+    const int adj0 = rb[0], adj1 = rb[1] - pre1, adj2 = rb[2] - pre2, adj3 = rb[3] - pre3;
+    for (int base = 0; base < tot; base += 16) {
+      float4 p[16];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) p[u][v] = sref[min(rb[u] + v, last)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) NN_CONSIDER_IF(p[u][v], rb[u] + v < re[u])
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      for (int s = rb[u] + 4; s < re[u]; s += 4) {
-        float4 q[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) q[v] = sref[min(s + v, re[u] - 1)];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) NN_CONSIDER(q[v])
+      for (int v = 0; v < 16; ++v) {
+        const int k = base + v;
+        int adj = k >= pre1 ? adj1 : adj0;
+        adj = k >= pre2 ? adj2 : adj;
+        adj = k >= pre3 ? adj3 : adj;
+        p[v] = ld_u32(sref, min(k + adj, last));
       }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) NN_CONSIDER_IF(p[v], base + v < tot)
+    }
   }
   NN_UNPACK(best, bi, bd)
 }
@@ -533,8 +566,8 @@ __device__ __forceinline__ void nn_search_global(const IcpShared &S, const float
 // the per-point terms into double-buffered LDS tiles while lane 0 of wave 0 adds the previous tile
 // in index order (the reference's `dist_mean += dist` chain); one barrier per tile.
 template <int MODE>
-__device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, int n, float thr, const float *Ropt,
-                             const float *Topt)
+__device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, float *bnd, int n, float thr,
+                                             const float *Ropt, const float *Topt)
 {
   constexpr bool parity = MODE == FL_ICP_PARITY;
   const int TQ = parity ? ICP_BS - 64 : ICP_BS;          // rows per tile: wave 0 only chains in parity mode
@@ -543,23 +576,52 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
   double dsum[1] = {0.0};
   float acc = 0.0f;
   const int ntiles = (n + TQ - 1) / TQ;
+  // The phase is one memory round trip + one barrier per tile, so the next tile's (coalesced) loads are
+  // issued before this tile is processed: the round trip overlaps the chain of the previous tile.
+  float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f}, pbnd = 0.f;
+  if (slot >= 0 && slot < n) {
+    const int i = slot;
+    pa[0] = ld_u32(mod, 3 * i); pa[1] = ld_u32(mod, 3 * i + 1); pa[2] = ld_u32(mod, 3 * i + 2);
+    pb[0] = ld_u32(ref, 3 * i); pb[1] = ld_u32(ref, 3 * i + 1); pb[2] = ld_u32(ref, 3 * i + 2);
+    if (Ropt) pbnd = ld_u32(bnd, i);
+  }
   for (int t = 0; t < ntiles; ++t) {
     if (slot >= 0) {
       const int i = t * TQ + slot;
       float term = 0.0f;
+      float a[3] = {pa[0], pa[1], pa[2]};
+      const float b0 = pb[0], b1 = pb[1], b2 = pb[2];
+      const float bprev = pbnd;
+      {
+        const int in = min(i + TQ, n - 1);                // clamped: unused past the end (this thread owns row i + TQ)
+        pa[0] = ld_u32(mod, 3 * in); pa[1] = ld_u32(mod, 3 * in + 1); pa[2] = ld_u32(mod, 3 * in + 2);
+        pb[0] = ld_u32(ref, 3 * in); pb[1] = ld_u32(ref, 3 * in + 1); pb[2] = ld_u32(ref, 3 * in + 2);
+        if (Ropt) pbnd = ld_u32(bnd, in);
+      }
       if (i < n) {
-        float a[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]};
-        if (Ropt && vvalid(a[2])) {                       // transformPoints in place (:28-45, :756)
-          float o[3];
-          mat_vec(Ropt, a, o);
-          a[0] = o[0] + Topt[0];
-          a[1] = o[1] + Topt[1];
-          a[2] = o[2] + Topt[2];
-          mod[3 * i] = a[0];
-          mod[3 * i + 1] = a[1];
-          mod[3 * i + 2] = a[2];
+        if (Ropt) {
+          float move = 0.0f;
+          if (vvalid(a[2])) {                             // transformPoints in place (:28-45, :756)
+            float o[3];
+            mat_vec(Ropt, a, o);
+            o[0] += Topt[0];
+            o[1] += Topt[1];
+            o[2] += Topt[2];
+            const float mx = o[0] - a[0], my = o[1] - a[1], mz = o[2] - a[2];
+            move = sqrtf(mx * mx + my * my + mz * mz);
+            a[0] = o[0];
+            a[1] = o[1];
+            a[2] = o[2];
+            mod[3 * i] = a[0];
+            mod[3 * i + 1] = a[1];
+            mod[3 * i + 2] = a[2];
+          }
+          bnd[i] = bprev + move;                          // triangle inequality: still reaches the old partner
+        } else {
+          // first bound: the index pair (n_ref >= n_model); NaN/inf simply disable the bound
+          const float ex = a[0] - b0, ey = a[1] - b1, ez = a[2] - b2;
+          bnd[i] = sqrtf(ex * ex + ey * ey + ez * ez);
         }
-        const float b0 = ref[3 * i], b1 = ref[3 * i + 1], b2 = ref[3 * i + 2];
         if (vvalid(b2) && vvalid(a[2])) {
           const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
           // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
@@ -608,6 +670,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
   float4 *sref = (float4 *)(wsb + L.sref);
   int *nn = (int *)(wsb + L.nn);
+  float *bnd = (float *)(wsb + L.bnd);
   int *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
 
   if (threadIdx.x == 0) {
@@ -618,6 +681,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     S.px = 0.f;
 #ifdef FL_ICP_DEBUG
     for (int i = 0; i < 8; ++i) { S.dbg[i] = 0; S.tacc[i] = 0; }
+    for (int i = 0; i < 24; ++i) { S.ta1[i] = 0; S.cells_it[i] = 0; S.wmax_it[i] = 0; }
     S.tlast = clock64();
 #endif
   }
@@ -639,13 +703,12 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
   // copyPoints(pts_model, pts_model_tmp) (:666-667): invalid points become Vec3f() = 0
   for (int i = threadIdx.x; i < n_model; i += blockDim.x)
     if (!vvalid(mod[3 * i + 2])) { mod[3 * i] = 0.f; mod[3 * i + 1] = 0.f; mod[3 * i + 2] = 0.f; }
-  for (int i = threadIdx.x; i < n_model; i += blockDim.x) nn[i] = ~i;   // first guess: the index pair (n_ref >= n_model)
   if (threadIdx.x == 0) {
     S.R[0] = S.R[4] = S.R[8] = 1.f;                      // R = eye, T = 0 (:644-645)
     S.dist_diff = FLT_MAX;
   }
   __syncthreads();
-  l2dist_phase<MODE>(S, mod, ref, n_model, FLT_MAX, nullptr, nullptr);                  // :670
+  l2dist_phase<MODE>(S, mod, ref, bnd, n_model, FLT_MAX, nullptr, nullptr);             // :670
 
   for (;;) {
     if (threadIdx.x == 0) S.go = (S.dist_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);   // :684
@@ -663,30 +726,32 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
 #pragma unroll
     for (int k = 0; k < 15; ++k) ds[k] = 0.0;
     if (iter > 1) {
-      // Phase A1 -- PointsCorresponding (:193-279): all four waves search.  The partner found last
-      // time (initially the index pair) bounds the search radius, so a converging cloud visits
-      // only a handful of candidates per point; the result is still the exact 1-NN.
-      for (int i = threadIdx.x; i < n_model; i += ICP_BS) {
-        const float qx = mod[3 * i], qy = mod[3 * i + 1], qz = mod[3 * i + 2];
-        const int prev = nn[i];
-        const int g = prev >= 0 ? prev : ~prev;
-        float bound;
-        {
-          const float dx = qx - ref[3 * g], dy = qy - ref[3 * g + 1], dz = qz - ref[3 * g + 2];
-          bound = dx * dx;
-          bound += dy * dy;
-          bound += dz * dz;
-        }
+      // Phase A1 -- PointsCorresponding (:193-279): all four waves search.  bnd[i] (distance to the partner found
+      // last time plus the motion since; initially the index pair) bounds the search radius, so a converging
+      // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.  Every load
+      // ahead of the search is coalesced and the next query's are issued before this query's search.
+      const float r_thr = uniform_f(sqrtf(thr));
+#ifdef FL_ICP_DEBUG
+      int dbg_area = 0;
+#endif
+      const NnGrid G = nn_grid(S);
+      int i = threadIdx.x;
+      float qx = 0.f, qy = 0.f, qz = 0.f, qb = 0.f;
+      if (i < n_model) { qx = ld_u32(mod, 3 * i); qy = ld_u32(mod, 3 * i + 1); qz = ld_u32(mod, 3 * i + 2); qb = ld_u32(bnd, i); }
+      for (; i < n_model; i += ICP_BS) {
+        const int in = min(i + ICP_BS, n_model - 1);       // clamped: unused past the end
+        const float nqx = ld_u32(mod, 3 * in), nqy = ld_u32(mod, 3 * in + 1), nqz = ld_u32(mod, 3 * in + 2), nqb = ld_u32(bnd, in);
         int cx0, cx1, cy0, cy1, j = -1;
         float d = NAN;
-        if (nn_ranges(S, qx, qy, qz, thr, bound, &cx0, &cx1, &cy0, &cy1))
-          nn_search_global(S, sref, cell_start, qx, qy, qz, cx0, cx1, cy0, cy1, &j, &d);
+        if (nn_ranges(G, qx, qy, qz, thr, r_thr, qb, &cx0, &cx1, &cy0, &cy1))
+          nn_search_global(G, sref, cell_start, qx, qy, qz, cx0, cx1, cy0, cy1, &j, &d);
 #ifdef FL_ICP_DEBUG
-        atomicAdd(&S.dbg[3], (cx1 - cx0 + 1) * (cy1 - cy0 + 1)); atomicAdd(&S.dbg[4], 1);
+        dbg_area += (cx1 - cx0 + 1) * (cy1 - cy0 + 1);   // per-lane, reduced once after the loop
 #endif
         const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
         if (keep) ++kept;
-        nn[i] = keep ? j : (j >= 0 ? ~j : (prev >= 0 ? ~prev : prev));
+        nn[i] = keep ? j : -1;
+        if (j >= 0) bnd[i] = sqrtf(d);                    // else: the old partner is still within qb
         if (!parity && keep) {
           const float m[3] = {qx, qy, qz}, r[3] = {ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]};
 #pragma unroll
@@ -696,8 +761,13 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
 #pragma unroll
           for (int q = 0; q < 3; ++q) { ds[9 + q] += (double)m[q]; ds[12 + q] += (double)r[q]; }
         }
+        qx = nqx; qy = nqy; qz = nqz; qb = nqb;
       }
       __syncthreads();                                   // nn[] complete
+#ifdef FL_ICP_DEBUG
+      atomicAdd(&S.dbg[3], dbg_area); atomicAdd(&S.cells_it[iter < 24 ? iter : 23], dbg_area);
+      if (threadIdx.x == 0) { S.dbg[4] += n_model; S.ta1[iter < 24 ? iter : 23] += clock64() - S.tlast; }
+#endif
       TSTAMP(2);
     }
     // Phase A2 (iteration 1: the only phase): rows in index order.  Parity mode: waves 1-3 write
@@ -707,6 +777,46 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
     const int ntiles = (parity || iter == 1) ? (rows + TQ - 1) / TQ : 0;
     float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
+    if (parity && iter > 1) {
+      // Two-deep register pipeline of the producers: a tile costs nn/mod loads (coalesced) and then the
+      // dependent gather ref[j]; tile t + 2's loads and tile t + 1's gather are in flight while tile t is
+      // written, so both round trips overlap the chains instead of adding up per tile.
+      int j1 = -1, j2 = -1;
+      float m1[3] = {0.f, 0.f, 0.f}, r1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+      if (slot >= 0) {
+        const int i0 = slot, i1 = TQ + slot;
+        if (i0 < rows) { j1 = ld_u32(nn, i0); m1[0] = ld_u32(mod, 3 * i0); m1[1] = ld_u32(mod, 3 * i0 + 1); m1[2] = ld_u32(mod, 3 * i0 + 2); }
+        if (i1 < rows) { j2 = ld_u32(nn, i1); m2[0] = ld_u32(mod, 3 * i1); m2[1] = ld_u32(mod, 3 * i1 + 1); m2[2] = ld_u32(mod, 3 * i1 + 2); }
+        const int g = max(j1, 0);
+        r1[0] = ld_u32(ref, 3 * g); r1[1] = ld_u32(ref, 3 * g + 1); r1[2] = ld_u32(ref, 3 * g + 2);
+      }
+      for (int t = 0; t < ntiles; ++t) {
+        if (slot >= 0) {
+          const int i3 = min((t + 2) * TQ + slot, rows - 1);     // clamped: unused past the end
+          const bool in3 = (t + 2) * TQ + slot < rows;
+          int j3 = ld_u32(nn, i3);
+          const float m3[3] = {ld_u32(mod, 3 * i3), ld_u32(mod, 3 * i3 + 1), ld_u32(mod, 3 * i3 + 2)};
+          j3 = in3 ? j3 : -1;
+          const int g = max(j2, 0);
+          const float r2[3] = {ld_u32(ref, 3 * g), ld_u32(ref, 3 * g + 1), ld_u32(ref, 3 * g + 2)};
+          const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f
+          float (*tile)[ICP_BS + 1] = S.prod[t & 1];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = have ? m1[a] * r1[b] : 0.0f;   // (*it_s) * (*it_ref).t()
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = have ? m1[q] : 0.0f; tile[12 + q][slot] = have ? r1[q] : 0.0f; }
+          j1 = j2;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { m1[q] = m2[q]; r1[q] = r2[q]; m2[q] = m3[q]; }
+          j2 = j3;
+        } else if (t > 0 && threadIdx.x < 15) {
+          acc = chain_tile(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+        }
+        __syncthreads();
+      }
+    } else
     for (int t = 0; t < ntiles; ++t) {
       if (slot >= 0) {
         const int i = t * TQ + slot;
@@ -799,7 +909,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     for (int k = 0; k < 3; ++k) To[k] = S.Topt[k];
     const float old_mean = S.dist_mean;
     __syncthreads();
-    l2dist_phase<MODE>(S, mod, ref, n_model, 3 * old_mean, Ro, To);                // :756, :778-780
+    l2dist_phase<MODE>(S, mod, ref, bnd, n_model, 3 * old_mean, Ro, To);           // :756, :778-780
     TSTAMP(5);
     if (threadIdx.x == 0) {
       S.dist_diff = old_mean - S.dist_mean;
@@ -811,6 +921,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     __syncthreads();
   }
 #ifdef FL_ICP_DEBUG
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    for (int it = 2; it < 22; ++it)
+      printf("  it %d A1 cycles %lld cells/query %.1f wave-max cells %.1f\n", it, S.ta1[it], (float)S.cells_it[it] / n_model,
+             (float)S.wmax_it[it] / ((n_model + 63) / 64));
   if (threadIdx.x == 0 && blockIdx.x == 0) printf("icp dbg: (unused %d %d) cells/query %.1f queries %d GX %d GY %d n %d | cycles grid %lld qorder %lld A1 %lld A2 %lld svd %lld B %lld | stage %lld search %lld | cands %d rowsteps %d wave-iters %d\n", S.dbg[0], S.dbg[1], S.dbg[4] ? (float)S.dbg[3] / S.dbg[4] : 0.f, S.dbg[4], S.GX, S.GY, n_ref, S.tacc[0], S.tacc[1], S.tacc[2], S.tacc[3], S.tacc[4], S.tacc[5], S.tacc[6], S.tacc[7], S.dbg[5], S.dbg[6], S.dbg[7]);
 #endif
   if (threadIdx.x == 0) {
@@ -883,7 +997,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_pipeline(IcpArgs a)
+__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
