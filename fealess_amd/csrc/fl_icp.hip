@@ -28,12 +28,14 @@
 #include <string.h>
 
 #define ICP_BS 256               // threads per frame workgroup = rows per LDS tile
-#ifdef FL_ICP_DEBUG
+#if defined(FL_ICP_DEBUG) || defined(FL_ICP_PHASES)
 #define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
 #else
 #define TSTAMP(k) do { } while (0)
 #endif
 #define ICP_MAX_THREADS ICP_BS
+#define ICP_TS (ICP_BS + 4)         // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4 keeps
+                                  // the 16 chain lanes of a b128 read on distinct bank groups
 
 // HBM layout of one frame's ICP workspace (n = capacity in points):
 //   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
@@ -111,8 +113,11 @@ struct IcpShared {
   // double-buffered LDS tiles feeding the sequential float32 chains (FL_ICP_PARITY):
   // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords, pad) of row r of tile b;
   // +1 column of padding puts the 16 chain lanes on 16 different banks
-  float prod[2][16][ICP_BS + 1];
-  float dtile[2][ICP_BS];
+  alignas(16) float prod[2][16][ICP_TS];
+  alignas(16) float dtile[2][ICP_BS];
+#ifdef FL_ICP_PHASES
+  long long tacc[16], tlast;
+#endif
 #ifdef FL_ICP_DEBUG
   int dbg[8];
   long long tacc[8], tlast;
@@ -324,16 +329,43 @@ __device__ __forceinline__ float chain_sum(const float *tab, int n, int stride, 
   return acc;
 }
 
-// one chain step over an LDS tile: acc += col[0], col[1], ... col[rows-1], strictly in order
+// one chain step over an LDS tile: acc += col[0], col[1], ... col[rows-1], strictly in order.
+// The adds are one dependent chain; what made a tile slow was the LDS read latency in front of every 16 of
+// them.  The column (16-byte aligned) is read 16 rows at a time with four ds_read_b128, two batches in flight:
+// batch B is issued before batch A is added and vice versa, so the reads overlap the chain.
+__device__ __forceinline__ void chain_load16(const float *col, float4 (&v)[4])
+{
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(col + 4 * u);
+}
+__device__ __forceinline__ float chain_add16(const float4 (&v)[4], float acc)
+{
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
+  return acc;
+}
 __device__ __forceinline__ float chain_tile(const float *col, int rows, float acc)
 {
   int r = 0;
-  for (; r + 16 <= rows; r += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = col[r + u];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc += v[u];
+  if (rows >= 16) {
+    float4 a[4], b[4];
+    chain_load16(col, a);
+    for (; r + 48 <= rows; r += 32) {
+      chain_load16(col + r + 16, b);
+      acc = chain_add16(a, acc);
+      chain_load16(col + r + 32, a);
+      acc = chain_add16(b, acc);
+    }
+    // here: batch at r is loaded in a; 16 <= rows - r < 48
+    if (r + 32 <= rows) {
+      chain_load16(col + r + 16, b);
+      acc = chain_add16(a, acc);
+      acc = chain_add16(b, acc);
+      r += 32;
+    } else {
+      acc = chain_add16(a, acc);
+      r += 16;
+    }
   }
   for (; r < rows; ++r) acc += col[r];
   return acc;
@@ -635,6 +667,7 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
       acc = chain_tile(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
     }
     if (parity) __syncthreads();
+
   }
   if (parity && ntiles > 0 && threadIdx.x == 0)
     acc = chain_tile(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
@@ -679,6 +712,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     S.iter = 0;
     S.n_corr = 0;
     S.px = 0.f;
+#ifdef FL_ICP_PHASES
+    for (int i = 0; i < 16; ++i) S.tacc[i] = 0;
+    S.tlast = clock64();
+#endif
 #ifdef FL_ICP_DEBUG
     for (int i = 0; i < 8; ++i) { S.dbg[i] = 0; S.tacc[i] = 0; }
     for (int i = 0; i < 24; ++i) { S.ta1[i] = 0; S.cells_it[i] = 0; S.wmax_it[i] = 0; }
@@ -800,7 +837,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           const int g = max(j2, 0);
           const float r2[3] = {ld_u32(ref, 3 * g), ld_u32(ref, 3 * g + 1), ld_u32(ref, 3 * g + 2)};
           const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f
-          float (*tile)[ICP_BS + 1] = S.prod[t & 1];
+          float (*tile)[ICP_TS] = S.prod[t & 1];
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -841,7 +878,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
         }
         if (parity) {
           // dropped pairs contribute an exact +0.0f, so the chains are branch-free
-          float (*tile)[ICP_BS + 1] = S.prod[t & 1];
+          float (*tile)[ICP_TS] = S.prod[t & 1];
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -934,6 +971,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     res->px_ratio = S.px;
     res->iters = S.iter;
     res->n_corr_last = S.n_corr;
+#ifdef FL_ICP_PHASES
+    // dev build only: phase cycles (grid, -, A1, A2, svd, B) of this workgroup instead of R
+    for (int i = 0; i < 6; ++i) res->R[i] = (float)S.tacc[i];
+#endif
   }
   __syncthreads();
 }
