@@ -84,6 +84,8 @@ SIGNATURES = {
     "fl_quantized_orientations": (_I, [_P, _P, _I, _I, _F, _P, _I]),
     "fl_quantized_normals": (_I, [_P, _P, _I, _I, _I, _I, _P, _I]),
     "fl_pyrdown_bgr": (_I, [_P, _P, _I, _I, _P, _I]),
+    "fl_resize_linear_bgr8": (_I, [_P, _P, _I, _I, _P, _I, _I, _I]),
+    "fl_resize_linear_u16": (_I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     "fl_lm_label_stride": (C.c_size_t, [_I, _I, _I]),
     "fl_build_linear_memories": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "fl_depth_to_3d": (_I, [_P, _P, _I, _I, _D, _D, _D, _D, _P, _I]),

@@ -71,6 +71,18 @@ class Context:
         self.check(self.lib.fl_pyrdown_bgr(self.h, _ptr(bgr), w, h, _ptr(out), L.FL_MEM_HOST))
         return out
 
+    def resize_linear(self, img, dw, dh):
+        """cv::resize(INTER_LINEAR) of PrepareInputData (obj_reco_lmicp.cpp:39-45): (h, w, 3) u8 or (h, w) u16."""
+        if img.dtype == np.uint16:
+            a = np.ascontiguousarray(img, np.uint16)
+            out = np.empty((dh, dw), np.uint16)
+            self.check(self.lib.fl_resize_linear_u16(self.h, _ptr(a), a.shape[1], a.shape[0], _ptr(out), dw, dh, L.FL_MEM_HOST))
+        else:
+            a = np.ascontiguousarray(img, np.uint8)
+            out = np.empty((dh, dw, 3), np.uint8)
+            self.check(self.lib.fl_resize_linear_bgr8(self.h, _ptr(a), a.shape[1], a.shape[0], _ptr(out), dw, dh, L.FL_MEM_HOST))
+        return out
+
     def build_linear_memories(self, quantized, T):
         q = np.ascontiguousarray(quantized, np.uint8)
         h, w = q.shape

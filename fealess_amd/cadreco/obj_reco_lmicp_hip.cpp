@@ -111,27 +111,42 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
       if (rgb[i].nHeight != K.nHeight || rgb[i].nWidth != K.nWidth || depth[i].nHeight != K.nHeight || depth[i].nWidth != K.nWidth)
         return (int)ERROR_INVALID_PARAM;
     }
-    if (K.nWidth != PROC_IMG_WIDTH) {
-      // the reference rescales to width 640 with cv::resize(INTER_LINEAR) (:39-45,229-249); that
-      // resampler is not reproduced yet -- reject rather than guess ("out of scope")
-      fprintf(stderr, "[fealess_hip] frames must be %d wide (got %d)\n", PROC_IMG_WIDTH, K.nWidth);
-      return (int)ERROR_INVALID_PARAM;
+    // zoom to width 640 (:229-249): w = 640, h = H * 640 / W (integer), cv::resize(INTER_LINEAR) of both images
+    const int w = PROC_IMG_WIDTH, h = K.nHeight * PROC_IMG_WIDTH / K.nWidth;
+    if (h <= 0) return (int)ERROR_INVALID_PARAM;
+    std::vector<const uint8_t *> bp(n);
+    std::vector<const uint16_t *> dp(n);
+    std::vector<std::vector<uint8_t> > zb;
+    std::vector<std::vector<uint16_t> > zd;
+    if (K.nWidth != w) {
+      zb.resize(n);
+      zd.resize(n);
+      for (int i = 0; i < n; ++i) {
+        zb[i].resize((size_t)w * h * 3);
+        zd[i].resize((size_t)w * h);
+        if (fl_resize_linear_bgr8(m_ctx, rgb[i].pData, K.nWidth, K.nHeight, zb[i].data(), w, h, FL_MEM_HOST) != FL_OK ||
+            fl_resize_linear_u16(m_ctx, depth[i].pData, K.nWidth, K.nHeight, zd[i].data(), w, h, FL_MEM_HOST) != FL_OK) {
+          fprintf(stderr, "[fealess_hip] %s\n", fl_last_error(m_ctx));
+          return (int)ERROR_INVALID_PARAM;
+        }
+        bp[i] = zb[i].data();
+        dp[i] = zd[i].data();
+      }
+    } else {
+      for (int i = 0; i < n; ++i) { bp[i] = rgb[i].pData; dp[i] = depth[i].pData; }
     }
-    if (m_w != K.nWidth || m_h != K.nHeight || n > m_batch) {
-      if (fl_detector_finalize(m_det, K.nWidth, K.nHeight, n > m_batch ? n : m_batch, 0) != FL_OK) {
+    if (m_w != w || m_h != h || n > m_batch) {
+      if (fl_detector_finalize(m_det, w, h, n > m_batch ? n : m_batch, 0) != FL_OK) {
         fprintf(stderr, "[fealess_hip] %s\n", fl_last_error(m_ctx));
         return (int)ERROR_INVALID_PARAM;
       }
-      m_w = K.nWidth;
-      m_h = K.nHeight;
+      m_w = w;
+      m_h = h;
       if (n > m_batch) m_batch = n;
     }
-    std::vector<const uint8_t *> bp(n);
-    std::vector<const uint16_t *> dp(n);
-    for (int i = 0; i < n; ++i) { bp[i] = rgb[i].pData; dp[i] = depth[i].pData; }
-    // NB: like the reference (:190) detection() gets the caller's un-zoomed intrinsics; identical here
-    // because only width-640 input is accepted
-    fl_intrinsics k = {K.nWidth, K.nHeight, K.dFx, K.dFy, K.dCx, K.dCy};
+    // NB: like the reference (:190) detection() gets the caller's UN-zoomed intrinsics together with the zoomed
+    // depth image (the zoomed copy only feeds SetCamIntrinsic, :236-244); identical when the input is 640 wide
+    fl_intrinsics k = {w, h, K.dFx, K.dFy, K.dCx, K.dCy};
     std::vector<fl_recognition_result> res(n);
     if (fl_recognize_batch(m_det, n, bp.data(), dp.data(), FL_MEM_HOST, &k, &m_params, res.data()) != FL_OK) {
       fprintf(stderr, "[fealess_hip] %s\n", fl_last_error(m_ctx));

@@ -528,3 +528,89 @@ extern "C" int fl_pyrdown_bgr(fl_context *ctx, const uint8_t *src, int w, int h,
   return run_stage(ctx, src, (size_t)w * h * 3, dst, (size_t)(w / 2) * (h / 2) * 3, 0, mem,
                    [&](const uint8_t *i, uint8_t *o, uint8_t *) { return fl_launch_pyrdown_bgr(ctx, i, 0, o, 0, 1, w, h); });
 }
+
+// ------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR) as CObjRecoLmICP::PrepareInputData applies it to frames that are not 640
+// wide (obj_reco_lmicp.cpp:39-45, 229-249).  OpenCV 3.x semantics restated in oracle/frontend_oracle.c
+// (orc_resize_linear_*): exact 2x2 decimation takes the INTER_AREA fast path, everything else two taps
+// per axis -- 11-bit fixed point for 8-bit data, float for 16-bit data.  One thread per output pixel;
+// this stage runs once per frame ahead of the batch and is HBM-bound (reads 4 source pixels).
+struct FlResizeTap { int ofs; float w0, w1; };
+__device__ __forceinline__ FlResizeTap fl_resize_tap(int d, int ssize, double scale)
+{
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  return {s, 1.f - f, f};
+}
+__device__ __forceinline__ int fl_sat_short(float v)
+{
+  const int r = (int)rintf(v);                           // saturate_cast<short>(float): round half even
+  return r < -32768 ? -32768 : r > 32767 ? 32767 : r;
+}
+
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void k_resize_linear(const T *__restrict__ src, int sw, int sh, T *__restrict__ dst, int dw,
+                                                       int dh, double scale_x, double scale_y, int area2)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  if (area2) {                                           // (a + b + c + d + 2) >> 2
+    const T *s0 = src + ((size_t)(2 * y) * sw + 2 * x) * CN, *s1 = s0 + (size_t)sw * CN;
+#pragma unroll
+    for (int c = 0; c < CN; ++c) dst[((size_t)y * dw + x) * CN + c] = (T)(((int)s0[c] + s0[CN + c] + s1[c] + s1[CN + c] + 2) >> 2);
+    return;
+  }
+  const FlResizeTap ty = fl_resize_tap(y, sh, scale_y), tx = fl_resize_tap(x, sw, scale_x);
+  const int y0 = ty.ofs, y1 = min(ty.ofs + 1, sh - 1), x0 = tx.ofs, x1 = min(tx.ofs + 1, sw - 1);
+  const T *r0 = src + (size_t)y0 * sw * CN, *r1 = src + (size_t)y1 * sw * CN;
+  if (sizeof(T) == 1) {
+    const int a0 = fl_sat_short(tx.w0 * 2048.f), a1 = fl_sat_short(tx.w1 * 2048.f);
+    const int b0 = fl_sat_short(ty.w0 * 2048.f), b1 = fl_sat_short(ty.w1 * 2048.f);
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+      const int S0 = (int)r0[x0 * CN + c] * a0 + (int)r0[x1 * CN + c] * a1;
+      const int S1 = (int)r1[x0 * CN + c] * a0 + (int)r1[x1 * CN + c] * a1;
+      dst[((size_t)y * dw + x) * CN + c] = (T)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CN; ++c) {
+      float S0 = (float)r0[x0 * CN + c] * tx.w0;
+      S0 = S0 + (float)r0[x1 * CN + c] * tx.w1;
+      float S1 = (float)r1[x0 * CN + c] * tx.w0;
+      S1 = S1 + (float)r1[x1 * CN + c] * tx.w1;
+      float v = S0 * ty.w0;
+      v = v + S1 * ty.w1;
+      const int r = (int)rintf(v);
+      dst[((size_t)y * dw + x) * CN + c] = (T)(r < 0 ? 0 : r > 65535 ? 65535 : r);
+    }
+  }
+}
+
+template <typename T, int CN>
+static int fl_resize_linear(fl_context *ctx, const T *src, int sw, int sh, T *dst, int dw, int dh, int mem)
+{
+  if (!ctx || !src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1) return FL_ERR_INVALID;
+  const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+  const int area2 = fabs(scale_x - 2.0) < 2.220446049250313e-16 && fabs(scale_y - 2.0) < 2.220446049250313e-16;
+  return run_stage(ctx, src, (size_t)sw * sh * CN * sizeof(T), dst, (size_t)dw * dh * CN * sizeof(T), 0, mem,
+                   [&](const uint8_t *i, uint8_t *o, uint8_t *) {
+                     hipLaunchKernelGGL((k_resize_linear<T, CN>), dim3((dw + 63) / 64, (dh + 3) / 4), dim3(256), 0, ctx->stream,
+                                        (const T *)i, sw, sh, (T *)o, dw, dh, scale_x, scale_y, area2);
+                     FL_HIP(ctx, hipGetLastError());
+                     return (int)FL_OK;
+                   });
+}
+
+extern "C" int fl_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, int mem)
+{
+  return fl_resize_linear<uint8_t, 3>(ctx, src, sw, sh, dst, dw, dh, mem);
+}
+
+extern "C" int fl_resize_linear_u16(fl_context *ctx, const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh, int mem)
+{
+  return fl_resize_linear<uint16_t, 1>(ctx, src, sw, sh, dst, dw, dh, mem);
+}

@@ -147,6 +147,10 @@ int  fl_quantized_normals(fl_context *ctx, const uint16_t *depth, int w, int h,
                           int distance_threshold, int difference_threshold, uint8_t *dst, int mem);
 /* cv::pyrDown on the colour image (linemod.cpp:443): w*h*3 -> (w/2)*(h/2)*3 */
 int  fl_pyrdown_bgr(fl_context *ctx, const uint8_t *src, int w, int h, uint8_t *dst, int mem);
+/* cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_LINEAR) as PrepareInputData applies it to frames
+ * that are not 640 wide (obj_reco_lmicp.cpp:39-45, 229-249: TImage2Mat(..., true)); BGR8 and u16 */
+int  fl_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, int mem);
+int  fl_resize_linear_u16(fl_context *ctx, const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh, int mem);
 /* spread + computeResponseMaps + linearize x8 (linemod.cpp:950-1088) for one quantized image:
  * out = 8 * fl_lm_label_stride(w,h,T) bytes, layout [label][T*T grid][(w/T)*(h/T)] + zero pad */
 size_t fl_lm_label_stride(int w, int h, int T);

@@ -98,6 +98,10 @@ int  orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
                       const orc_bank *banks, int n_classes, float threshold,
                       orc_match *out, int cap, int *n_total, uint8_t *quantized_out);
 
+/* cv::resize(INTER_LINEAR) of PrepareInputData (obj_reco_lmicp.cpp:39-45, 248-249); cn = channels */
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh);
+void orc_resize_linear_u16(const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh);
+
 /* same with the optional per-modality masks of Detector::match (linemod.hpp:319-327); NULL = empty */
 int  orc_match_images_masked(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
                              int levels, const int *T_at_level,

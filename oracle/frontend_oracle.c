@@ -354,3 +354,107 @@ int orc_match_images(const uint8_t *bgr, const uint16_t *depth, int w0, int h0,
   return orc_match_images_masked(bgr, depth, w0, h0, levels, T_at_level, banks, n_classes, threshold, NULL, NULL, out, cap,
                                  n_total, quantized_out);
 }
+
+/* ---- cv::resize(..., INTER_LINEAR) as PrepareInputData uses it (obj_reco_lmicp.cpp:39-45, 248-249:
+ * `TImage2Mat(img, w, h, type, true)` -> interpolation flag 1) -------------------------------------
+ * OpenCV 3.x imgproc/imgwarp.cpp restated (un-vendored; not checkable here):
+ *  - scale = src/dst (double); an exact 2x2 decimation is redirected to the INTER_AREA fast path
+ *    `(a + b + c + d + 2) >> 2`;
+ *  - otherwise resizeGeneric_: fx = (float)((dx + 0.5) * scale_x - 0.5), sx = floor(fx), clamped at both
+ *    borders with a zero fraction; two taps per axis;
+ *  - 8-bit: taps = saturate_cast<short>(w * 2048) (round half even), horizontal sums in int,
+ *    vertical `(((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2`;
+ *  - 16-bit: float taps, horizontal `S[sx] * a0 + S[sx + cn] * a1`, vertical `S0 * b0 + S1 * b1`,
+ *    saturate_cast<ushort> (round half even). */
+static int resize_is_area2(int sw, int sh, int dw, int dh)
+{
+  const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+  const int ix = (int)lrint(scale_x), iy = (int)lrint(scale_y);
+  return fabs(scale_x - ix) < 2.220446049250313e-16 && fabs(scale_y - iy) < 2.220446049250313e-16 && ix == 2 && iy == 2;
+}
+
+static void resize_taps(int d, int ssize, int dsize, int *ofs, float *w0, float *w1)
+{
+  const double scale = (double)ssize / dsize;
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  *ofs = s;
+  *w0 = 1.f - f;
+  *w1 = f;
+}
+
+static int round_half_even_f(float v) { return (int)lrintf(v); }
+static short sat_short(float v)
+{
+  int r = round_half_even_f(v);
+  return (short)(r < -32768 ? -32768 : r > 32767 ? 32767 : r);
+}
+
+void orc_resize_linear_u8(const uint8_t *src, int sw, int sh, int cn, uint8_t *dst, int dw, int dh)
+{
+  if (resize_is_area2(sw, sh, dw, dh)) {
+    for (int y = 0; y < dh; ++y)
+      for (int x = 0; x < dw; ++x)
+        for (int c = 0; c < cn; ++c) {
+          const uint8_t *s0 = src + ((size_t)(2 * y) * sw + 2 * x) * cn + c, *s1 = s0 + (size_t)sw * cn;
+          dst[((size_t)y * dw + x) * cn + c] = (uint8_t)((s0[0] + s0[cn] + s1[0] + s1[cn] + 2) >> 2);
+        }
+    return;
+  }
+  for (int y = 0; y < dh; ++y) {
+    int sy;
+    float fy0, fy1;
+    resize_taps(y, sh, dh, &sy, &fy0, &fy1);
+    /* rows sy and sy + 1, clipped (resizeGeneric_Invoker: clip(sy0 - ksize2 + 1 + k, 0, ssize.height)) */
+    const int y0 = sy < 0 ? 0 : sy >= sh ? sh - 1 : sy, y1 = sy + 1 >= sh ? sh - 1 : sy + 1;
+    const short b0 = sat_short(fy0 * 2048.f), b1 = sat_short(fy1 * 2048.f);
+    for (int x = 0; x < dw; ++x) {
+      int sx;
+      float fx0, fx1;
+      resize_taps(x, sw, dw, &sx, &fx0, &fx1);
+      const short a0 = sat_short(fx0 * 2048.f), a1 = sat_short(fx1 * 2048.f);
+      const int sx1 = sx + 1 < sw ? sx + 1 : sx;       /* a1 == 0 there (dx >= xmax: D = S[sx] * ONE) */
+      for (int c = 0; c < cn; ++c) {
+        const int S0 = src[((size_t)y0 * sw + sx) * cn + c] * a0 + src[((size_t)y0 * sw + sx1) * cn + c] * a1;
+        const int S1 = src[((size_t)y1 * sw + sx) * cn + c] * a0 + src[((size_t)y1 * sw + sx1) * cn + c] * a1;
+        const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        dst[((size_t)y * dw + x) * cn + c] = (uint8_t)v;     /* `uchar(...)`: plain truncation, value is in range */
+      }
+    }
+  }
+}
+
+void orc_resize_linear_u16(const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh)
+{
+  if (resize_is_area2(sw, sh, dw, dh)) {
+    for (int y = 0; y < dh; ++y)
+      for (int x = 0; x < dw; ++x) {
+        const uint16_t *s0 = src + (size_t)(2 * y) * sw + 2 * x, *s1 = s0 + sw;
+        dst[(size_t)y * dw + x] = (uint16_t)((s0[0] + s0[1] + s1[0] + s1[1] + 2) >> 2);
+      }
+    return;
+  }
+  for (int y = 0; y < dh; ++y) {
+    int sy;
+    float b0, b1;
+    resize_taps(y, sh, dh, &sy, &b0, &b1);
+    const int y0 = sy < 0 ? 0 : sy >= sh ? sh - 1 : sy, y1 = sy + 1 >= sh ? sh - 1 : sy + 1;
+    for (int x = 0; x < dw; ++x) {
+      int sx;
+      float a0, a1;
+      resize_taps(x, sw, dw, &sx, &a0, &a1);
+      const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+      float S0 = (float)src[(size_t)y0 * sw + sx] * a0;
+      S0 = S0 + (float)src[(size_t)y0 * sw + sx1] * a1;
+      float S1 = (float)src[(size_t)y1 * sw + sx] * a0;
+      S1 = S1 + (float)src[(size_t)y1 * sw + sx1] * a1;
+      float v = S0 * b0;
+      v = v + S1 * b1;
+      int r = round_half_even_f(v);
+      dst[(size_t)y * dw + x] = (uint16_t)(r < 0 ? 0 : r > 65535 ? 65535 : r);
+    }
+  }
+}

@@ -169,6 +169,23 @@ def resize_nn_half(q):
     return out
 
 
+def resize_linear_u8(img, dw, dh):
+    a = np.ascontiguousarray(img, np.uint8)
+    sh, sw = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    out = np.zeros((dh, dw) + (() if a.ndim == 2 else (cn,)), np.uint8)
+    lib().orc_resize_linear_u8(_p(a), sw, sh, cn, _p(out), dw, dh)
+    return out
+
+
+def resize_linear_u16(img, dw, dh):
+    a = np.ascontiguousarray(img, np.uint16)
+    sh, sw = a.shape
+    out = np.zeros((dh, dw), np.uint16)
+    lib().orc_resize_linear_u16(_p(a), sw, sh, _p(out), dw, dh)
+    return out
+
+
 def quantize_pyramid(bgr, depth, levels):
     """The two default modalities' quantized images per level, order [l*2 + m]."""
     out = []

@@ -108,3 +108,14 @@ def test_match_with_masks_bit_exact(ctx, oracle, which):
     with pytest.raises(api.FealessError):
         det.match(sc["bgr"], sc["depth"], thr, masks=[mc])           # masks.size() != modalities.size()
     det.close()
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(1280, 960, 640, 480), (800, 600, 640, 480), (320, 240, 640, 480), (1024, 768, 640, 480),
+                                         (641, 481, 640, 480), (1280, 720, 640, 360), (37, 23, 64, 48)])
+def test_resize_linear_bit_exact(ctx, oracle, sw, sh, dw, dh):
+    """PrepareInputData's cv::resize(INTER_LINEAR) (obj_reco_lmicp.cpp:39-45, 248-249) for BGR8 and depth16."""
+    rng = np.random.default_rng(sw)
+    bgr = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    depth = rng.integers(0, 65536, (sh, sw)).astype(np.uint16)
+    assert np.array_equal(ctx.resize_linear(bgr, dw, dh), oracle.resize_linear_u8(bgr, dw, dh))
+    assert np.array_equal(ctx.resize_linear(depth, dw, dh), oracle.resize_linear_u16(depth, dw, dh))

@@ -99,6 +99,17 @@ def test_cadreco_facade_end_to_end(tmp_path, oracle):
     assert pose.reshape(4, 4)[3].tolist() == [0, 0, 0, 1]
     assert reco(kw=320) == C.c_int(0x80000001).value         # size != intrinsics size -> ERROR_INVALID_PARAM (:223-227)
     assert reco(ts=-1.0) == C.c_int(0x80000001).value        # negative timestamp (CheckTImage :35)
+    # a 1280x960 frame is zoomed to 640x480 with cv::resize(INTER_LINEAR) (:229-249) while detection() still gets
+    # the caller's un-zoomed intrinsics (:190).  Pixel replication makes the zoomed frame equal the 640x480 one.
+    bgr2 = np.ascontiguousarray(np.repeat(np.repeat(bgr, 2, axis=0), 2, axis=1))
+    depth2 = np.ascontiguousarray(np.repeat(np.repeat(depth, 2, axis=0), 2, axis=1))
+    rc = lib.cadreco_recognition(h, bgr2.ctypes.data_as(C.c_void_p), depth2.ctypes.data_as(C.c_void_p), 1280, 960, C.c_double(1.0),
+                                 1280, 960, C.c_double(2 * fx), C.c_double(2 * fy), C.c_double(2 * cx), C.c_double(2 * cy),
+                                 C.byref(n), pose.ctypes.data_as(C.c_void_p), tag, 64)
+    assert rc == 0 and n.value == 1
+    exp2 = oracle.recognition(bgr, depth, (2 * fx, 2 * fy, 2 * cx, 2 * cy), [5, 8], sc["bank"], 75.0, 10, 0.5, 0.01)
+    assert np.abs(pose.reshape(4, 4) - exp2["pose"]).max() <= 1e-4
+    assert reco() == 0 and np.abs(pose.reshape(4, 4) - exp["pose"]).max() <= 1e-4      # back to 640x480 (re-finalize not needed)
     lib.cadreco_destroy(h)
 
 

@@ -305,3 +305,25 @@ def test_masked_match_semantics(oracle):
     q[3] = q[3] * (md[::2, ::2] != 0)
     exp, n_exp = oracle.match_quantized(q, 320, 240, T, bank, 60.0)
     assert n_got == n_exp and np.array_equal(got, exp)
+
+
+def test_resize_linear_properties(oracle):
+    """cv::resize(INTER_LINEAR) restatement (obj_reco_lmicp.cpp:39-45): exact 2x2 decimation is the rounded box mean
+    (OpenCV redirects it to INTER_AREA), constants are preserved, a ramp stays the ramp it samples."""
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    box = ((a[0::2, 0::2].astype(int) + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(oracle.resize_linear_u8(a, 64, 48), box)
+    d = rng.integers(0, 4000, (96, 128)).astype(np.uint16)
+    boxd = ((d[0::2, 0::2].astype(int) + d[0::2, 1::2] + d[1::2, 0::2] + d[1::2, 1::2] + 2) >> 2).astype(np.uint16)
+    assert np.array_equal(oracle.resize_linear_u16(d, 64, 48), boxd)
+    assert (oracle.resize_linear_u8(np.full((30, 40, 3), 77, np.uint8), 64, 48) == 77).all()
+    assert (oracle.resize_linear_u16(np.full((30, 40), 1234, np.uint16), 64, 48) == 1234).all()
+    ramp = (np.arange(80)[None, :] * 10 + np.zeros((60, 1))).astype(np.uint16)
+    r = oracle.resize_linear_u16(ramp, 64, 48)
+    x = (np.arange(64) + 0.5) * 1.25 - 0.5                       # source coordinate of every output column
+    assert np.array_equal(r[7, 1:-1], np.rint(x[1:-1] * 10).astype(np.uint16)) and (r == r[0]).all()
+    r8 = oracle.resize_linear_u8((np.arange(80)[None, :, None] * 3 + np.zeros((60, 1, 3))).astype(np.uint8), 64, 48)
+    assert np.abs(r8[5, 1:-1, 0].astype(float) - x[1:-1] * 3).max() < 1.0   # 11-bit taps, truncating shifts
+    up = oracle.resize_linear_u8(a, 256, 192)                     # enlarging: borders replicate (sx < 0 -> 0, fx = 0)
+    assert np.array_equal(up[0, 0], a[0, 0]) and np.array_equal(up[-1, -1], a[-1, -1])
