@@ -419,7 +419,10 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
     if (!(xmax >= xmin)) { xmin = xmax = 0.f; ymin = ymax = 0.f; }
     const float dx = xmax - xmin, dy = ymax - ymin;
     float c = sqrtf((dx * dy) / (float)(n_ref > 0 ? n_ref : 1));   // about one point per cell on a dense surface
-    if (!(c > 0.25f)) c = 0.25f;
+    // scale-free guards: a (nearly) collinear cloud gets cells of extent / sqrt(n); coincident points one cell
+    const float ext = fmaxf(dx, dy);
+    if (!(c > ext * 1e-4f)) c = ext / sqrtf((float)(n_ref > 0 ? n_ref : 1));
+    if (!(c > 0.f) || !isfinite(c)) c = 1.0f;
     int GX, GY;
     for (;;) {
       GX = (int)(dx / c) + 1;

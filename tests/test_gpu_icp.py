@@ -167,3 +167,31 @@ def test_recognition_matches_oracle(ctx, oracle, seed):
             assert np.array_equal(_bits(g["pose"]), _bits(exp["pose"]))
         assert got[0]["found"] == 1
     det.close()
+
+
+@pytest.mark.parametrize("scale", [1e-3, 37.0])
+def test_icp_is_scale_free(ctx, oracle, scale):
+    """Clouds in metres (or any other unit): the search grid adapts its cell size, results stay bit-exact."""
+    ref, model = _clouds(8, 4000)
+    ref, model = (ref * np.float32(scale)).astype(np.float32), (model * np.float32(scale)).astype(np.float32)
+    if scale > 1:                        # keep z under the reference's validity bound (z <= 900, common.cpp:261-266)
+        ref[:, 2] -= np.float32(600.0 * scale - 100.0)
+        model[:, 2] -= np.float32(600.0 * scale - 100.0)
+    got = ctx.icp_cloud_to_cloud_ex(ref, model, 8, 0.0, -3.0e38)
+    exp = oracle.icp(ref, model, 8, 0.0, -3.0e38)
+    assert got["iters"] == exp["iters"] == 8 and got["n_corr_last"] == exp["n_corr_last"]
+    assert np.array_equal(_bits(got["R"]), _bits(exp["R"])) and np.array_equal(_bits(got["T"]), _bits(exp["T"]))
+
+
+def test_icp_degenerate_clouds(ctx, oracle):
+    """Collinear and coincident reference points (zero-area bounding box) do not break the grid."""
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.uniform(0, 100, 500)).astype(np.float32)
+    ref = np.stack([t, np.full_like(t, 3.0), np.full_like(t, 400.0)], 1)
+    model = (ref + np.float32([0.3, 0.0, 0.2])).astype(np.float32)
+    for r, m in ((ref, model), (np.repeat(ref[:1], 50, 0), np.repeat(model[:1], 50, 0))):
+        got = ctx.icp_cloud_to_cloud_ex(r, m, 4, 0.0, -3.0e38)
+        exp = oracle.icp(r, m, 4, 0.0, -3.0e38)
+        assert got["iters"] == exp["iters"] and got["n_corr_last"] == exp["n_corr_last"]
+        assert np.array_equal(np.isnan(got["R"]), np.isnan(exp["R"]))
+        assert np.abs(np.nan_to_num(got["R"]) - np.nan_to_num(exp["R"])).max() <= POSE_TOL
