@@ -194,12 +194,12 @@ def main():
     traffic = None
     traffic_detail = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_b1024.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_b1024.json")))
         if pm["batch"] == B and pm["templates"] == bank.n_pyramids and args.icp_mode == "parity":
             kd = pm["kernels"][dom if dom != "k_icp_pipeline" else "k_icp_pipeline<0>"]
             traffic = (kd["FETCH_SIZE"] + kd["WRITE_SIZE"]) * 1024.0          # bytes per launch, raw counters
             traffic_detail = dict(fetch_bytes=kd["FETCH_SIZE"] * 1024, write_bytes=kd["WRITE_SIZE"] * 1024,
-                                  source="profiles/r01_pmc_b1024.json",
+                                  source="profiles/r01_final_pmc_b1024.json",
                                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; gfx950 FETCH_SIZE "
                                        "under-counts wide coalesced reads by up to 2x (this kernel's reads are mostly "
                                        "4-16 B gathers: uncalibrated), so true HBM reads lie between 1x and 2x fetch_bytes")

@@ -1,0 +1,40 @@
+"""Turn the raw rocprofv3 output of tools/profile_round.sh (under gpurun_out/) into the committed summaries:
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_b<batch>.json, profiles/<tag>_bench.json.
+
+usage: python tools/profile_summarise.py r01_final [batch]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+out = os.path.join(ROOT, "profiles")
+src = os.path.join(ROOT, "gpurun_out")
+
+stats = glob.glob(os.path.join(src, "prof_final", "**", "*kernel_stats.csv"), recursive=True)
+assert stats, "no kernel_stats.csv under gpurun_out/prof_final"
+shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(lambda: collections.defaultdict(set))
+for f in glob.glob(os.path.join(src, "pmc_final_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+kernels = {k: {c: acc[k][c] / max(1, len(disp[k][c])) for c in sorted(acc[k])} for k in sorted(acc) if k.startswith("k_") or "k_" in k}
+json.dump({
+    "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --batch %d --no-cpu-baseline" % batch,
+    "note": "per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: FETCH_SIZE under-counts wide "
+            "coalesced reads by up to 2x -- MI355X_MICROARCH.md); SQ_* cycle counters are quad-cycles summed over waves; "
+            "separate passes per counter group (tools/profile_round.sh)",
+    "batch": batch, "templates": 360, "kernels": kernels}, open(os.path.join(out, f"{tag}_pmc_b{batch}.json"), "w"), indent=1)
+line = [l for l in open(os.path.join(src, "bench_final.json")) if l.startswith("{")][-1]
+open(os.path.join(out, f"{tag}_bench.json"), "w").write(line)
+print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag)))
