@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restric
   const int xc = clampi(x, 0, w - 1);
   const int y0 = chunk * CQ_CH, y1 = min(h, y0 + CQ_CH);
   const bool interior = __all(xc >= 3 && xc <= w - 5);
-  const int kk[7] = {8, 28, 56, 72, 56, 28, 8};
 
   int H[7][3];
   int center = clampi(y0 - 2, 0, h - 1);
@@ -124,9 +123,17 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restric
       center = c;
     }
     // vertical pass + the single rounding of the 8-bit GaussianBlur: (acc + 2^15) >> 16
-    int v0 = 0, v1 = 0, v2 = 0;
+    // H <= 255 * 256, so every product fits 24 bits: __umul24 is a full-rate multiply where the generic 32-bit one
+    // runs at quarter rate; the kernel is symmetric, so 4 multiplies per channel instead of 7
+    int v0, v1, v2;
+    {
+      int vv[3];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) { v0 += kk[i] * H[i][0]; v1 += kk[i] * H[i][1]; v2 += kk[i] * H[i][2]; }
+      for (int ch = 0; ch < 3; ++ch)
+        vv[ch] = (int)(__umul24(8u, (unsigned)(H[0][ch] + H[6][ch])) + __umul24(28u, (unsigned)(H[1][ch] + H[5][ch])) +
+                       __umul24(56u, (unsigned)(H[2][ch] + H[4][ch])) + __umul24(72u, (unsigned)H[3][ch]));
+      v0 = vv[0]; v1 = vv[1]; v2 = vv[2];
+    }
     const uint32_t S = (uint32_t)((v0 + (1 << 15)) >> 16) | ((uint32_t)((v1 + (1 << 15)) >> 16) << 8) |
                        ((uint32_t)((v2 + (1 << 15)) >> 16) << 16);
     const uint32_t L = (uint32_t)__shfl_up((int)S, 1, 64), R = (uint32_t)__shfl_down((int)S, 1, 64);
@@ -160,9 +167,12 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restric
     qi = qi < 0 ? 0 : (qi > 255 ? 255 : qi);
     // hysteresisGradient :316-335: border rows/cols zeroed, interior folded to 8 bins
     const bool inside = ys > 0 && ys < h - 1 && x > 0 && x < w - 1;
+    // the vote counts the labels of the 3x3 neighbourhood in eight 4-bit counters; each pixel contributes the
+    // counter word of its own label, the row sum x-1, x, x+1 is formed once and kept for three rows
     const uint32_t q = inside ? (uint32_t)(qi & 7) : 0u;
-    const uint32_t ql = (uint32_t)__shfl_up((int)q, 1, 64), qr = (uint32_t)__shfl_down((int)q, 1, 64);
-    Qp[0] = Qp[1]; Qp[1] = Qp[2]; Qp[2] = q | (ql << 8) | (qr << 16);
+    const uint32_t oh = 1u << (4 * q);
+    const uint32_t ohl = (uint32_t)__shfl_up((int)oh, 1, 64), ohr = (uint32_t)__shfl_down((int)oh, 1, 64);
+    Qp[0] = Qp[1]; Qp[1] = Qp[2]; Qp[2] = oh + ohl + ohr;
     Mg[0] = Mg[1]; Mg[1] = Mg[2]; Mg[2] = (float)bmag;
     if (yv < y0 + 2) continue;
     // 3x3 majority vote at row yo = yv - 2 (:337-384)
@@ -170,20 +180,11 @@ __global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restric
     if (lane >= 2 && lane < 2 + CQ_COLS && x < w && yo < y1) {
       uint8_t res = 0;
       if (yo >= 1 && yo < h - 1 && x >= 1 && x < w - 1 && Mg[1] > threshold_sq) {
-        unsigned hist = 0;                               // 8 x 4-bit counters
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          hist += 1u << (4 * (Qp[r] & 0xFFu));
-          hist += 1u << (4 * ((Qp[r] >> 8) & 0xFFu));
-          hist += 1u << (4 * ((Qp[r] >> 16) & 0xFFu));
-        }
-        int max_votes = 0, index = -1;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-          const int v = (hist >> (4 * b)) & 15;
-          if (max_votes < v) { index = b; max_votes = v; }
-        }
-        if (max_votes >= 5) res = (uint8_t)(1 << index);
+        // :337-384: the first label with the most votes wins if it has >= 5 of the 9 -- a strict majority, so it
+        // is the only counter >= 5: adding 3 to every counter (max 9 + 3, no carry) sets bit 3 exactly there
+        const unsigned hist = Qp[0] + Qp[1] + Qp[2];       // 8 x 4-bit counters
+        const unsigned maj = (hist + 0x33333333u) & 0x88888888u;
+        if (maj) res = (uint8_t)(1u << ((__ffs((int)maj) - 4) >> 2));
       }
       out[(size_t)yo * w + x] = res;
     }

@@ -34,6 +34,9 @@
 #define TSTAMP(k) do { } while (0)
 #endif
 #define ICP_MAX_THREADS ICP_BS
+#ifndef FL_ICP_NB
+#define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
+#endif
 #define ICP_TS (ICP_BS + 4)         // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4 keeps
                                   // the 16 chain lanes of a b128 read on distinct bank groups
 
@@ -579,10 +582,10 @@ __device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *
     const int pre1 = re[0] - rb[0], pre2 = pre1 + (re[1] - rb[1]), pre3 = pre2 + (re[2] - rb[2]);
     const int tot = pre3 + (re[3] - rb[3]);
     const int adj0 = rb[0], adj1 = rb[1] - pre1, adj2 = rb[2] - pre2, adj3 = rb[3] - pre3;
-    for (int base = 0; base < tot; base += 16) {
-      float4 p[16];
+    for (int base = 0; base < tot; base += FL_ICP_NB) {
+      float4 p[FL_ICP_NB];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
+      for (int v = 0; v < FL_ICP_NB; ++v) {
         const int k = base + v;
         int adj = k >= pre1 ? adj1 : adj0;
         adj = k >= pre2 ? adj2 : adj;
@@ -590,7 +593,7 @@ __device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *
         p[v] = ld_u32(sref, min(k + adj, last));
       }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) NN_CONSIDER_IF(p[v], base + v < tot)
+      for (int v = 0; v < FL_ICP_NB; ++v) NN_CONSIDER_IF(p[v], base + v < tot)
     }
   }
   NN_UNPACK(best, bi, bd)
