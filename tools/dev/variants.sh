@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev only: build fl_icp.hip with different -D flags on the GPU box and bench each (usage: dev_variants.sh "flags1" "flags2" ...)
+# dev only (tools/dev/README.md): build fl_icp.hip with different -D flags on the GPU box and bench each (usage: dev_variants.sh "flags1" "flags2" ...)
 cd fealess_amd/csrc
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize"
 for v in "$@"; do
