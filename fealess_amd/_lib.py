@@ -79,6 +79,7 @@ SIGNATURES = {
     "fl_detector_add_class": (_I, [_P, C.c_char_p, _I, _P, _P, _I, _P]),
     "fl_detector_set_model_depths": (_I, [_P, _I, _I, _I, _P, _I, _I, _I]),
     "fl_detector_finalize": (_I, [_P, _I, _I, _I, _I]),
+    "fl_detector_set_class_filter": (_I, [_P, C.POINTER(C.c_char_p), _I]),
     "fl_detector_num_templates": (_I, [_P]),
     "fl_detector_num_classes": (_I, [_P]),
     "fl_quantized_orientations": (_I, [_P, _P, _I, _I, _F, _P, _I]),

@@ -164,6 +164,12 @@ class Detector:
         self.banks.append(bank)
         self.banks.sort(key=lambda b: b.class_id)
 
+    def set_class_filter(self, class_ids=()):
+        """Detector::match's class_ids (linemod.cpp:1418-1434): () = all classes."""
+        ids = [c.encode() for c in class_ids]
+        arr = (C.c_char_p * max(1, len(ids)))(*ids) if ids else None
+        self.ctx.check(self.lib.fl_detector_set_class_filter(self.h, arr, len(ids)))
+
     def finalize(self, w0, h0, max_batch=1, max_candidates=0):
         # model depth renders first (class order = sorted class ids)
         for ci, b in enumerate(self.banks):

@@ -143,6 +143,7 @@ static void free_device_tables(fl_detector *det)
   (void)hipFree(det->d_pyr);
   (void)hipFree(det->d_poses);
   (void)hipFree(det->d_class_first);
+  (void)hipFree(det->d_pyr_enabled);
   (void)hipFree((void *)det->d_depth_ptrs);
   (void)hipFree(det->d_ws);
   (void)hipFree(det->d_results);
@@ -154,6 +155,7 @@ static void free_device_tables(fl_detector *det)
   det->d_pyr = nullptr;
   det->d_poses = nullptr;
   det->d_class_first = nullptr;
+  det->d_pyr_enabled = nullptr;
   det->d_depth_ptrs = nullptr;
   det->d_ws = nullptr;
   det->d_results = nullptr;
@@ -248,6 +250,34 @@ static int upload(fl_context *ctx, const std::vector<T> &v, T **out)
   FL_HIP(ctx, hipMalloc((void **)out, bytes));
   if (!v.empty()) FL_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return FL_OK;
+}
+
+// Detector::match's class_ids (linemod.cpp:1418-1434): empty = every class; otherwise only the listed classes
+// that exist are matched (unknown ids are ignored, repeats change nothing after sort + unique).
+int fl_apply_class_filter(fl_detector *det)
+{
+  fl_context *ctx = det->ctx;
+  std::vector<uint8_t> en;
+  for (size_t ci = 0; ci < det->classes.size(); ++ci) {
+    bool on = det->class_filter.empty();
+    for (size_t k = 0; k < det->class_filter.size(); ++k) on = on || det->class_filter[k] == det->classes[ci].id;
+    en.insert(en.end(), (size_t)det->classes[ci].n_pyramids, on ? 1 : 0);
+  }
+  if (en.empty()) return FL_OK;
+  if (!det->d_pyr_enabled) FL_HIP(ctx, hipMalloc((void **)&det->d_pyr_enabled, en.size()));
+  FL_HIP(ctx, hipMemcpyAsync(det->d_pyr_enabled, en.data(), en.size(), hipMemcpyHostToDevice, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FL_OK;
+}
+
+extern "C" int fl_detector_set_class_filter(fl_detector *det, const char *const *class_ids, int n)
+{
+  if (!det || n < 0 || (n > 0 && !class_ids)) return FL_ERR_INVALID;
+  det->class_filter.clear();
+  for (int i = 0; i < n; ++i) det->class_filter.push_back(class_ids[i] ? class_ids[i] : "");
+  if (!det->finalized) return FL_OK;                     // applied by fl_detector_finalize
+  FL_HIP(det->ctx, hipSetDevice(det->ctx->device));
+  return fl_apply_class_filter(det);
 }
 
 extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_batch, int max_candidates)
@@ -394,6 +424,7 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   if ((rc = upload(ctx, pyr, &det->d_pyr))) return rc;
   if ((rc = upload(ctx, poses, &det->d_poses))) return rc;
   if ((rc = upload(ctx, class_first, &det->d_class_first))) return rc;
+  if ((rc = fl_apply_class_filter(det))) return rc;
   {
     const uint16_t **tmp = nullptr;
     if ((rc = upload(ctx, depth_ptrs, (const uint16_t ***)&tmp))) return rc;

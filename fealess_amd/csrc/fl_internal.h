@@ -107,6 +107,8 @@ struct fl_detector {
   FlFineFeat *d_fine_feat = nullptr;
   FlPyrInfo *d_pyr = nullptr;            // n_pyr
   int *d_class_first = nullptr;          // first global pyramid index of each class
+  uint8_t *d_pyr_enabled = nullptr;      // n_pyr: 0 = its class is excluded by the class filter of match()
+  std::vector<std::string> class_filter; // empty = all classes (Detector::match's class_ids)
   float *d_poses = nullptr;              // n_pyr * 13 (zeros when absent)
   const uint16_t **d_depth_ptrs = nullptr; // n_pyr pointers to model depth (0.1mm) or null
   int depth_w = 0, depth_h = 0;
@@ -130,6 +132,8 @@ struct fl_detector {
   bool have_times = false;
   double scan_bytes_per_frame = 0;       // SURVEY 8(d) B_tmpl summed over the bank
 };
+
+int fl_apply_class_filter(fl_detector *det);
 
 // ---- stage launchers (defined in the per-domain .hip files) ---------------------------------
 // linemod

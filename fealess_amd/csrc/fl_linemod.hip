@@ -245,6 +245,7 @@ int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_strid
 struct ScanArgs {
   const FlScanHdr *hdr;
   const uint32_t *offs;
+  const uint8_t *enabled;    // per pyramid: class selected by match()'s class_ids (linemod.cpp:1418-1434)
   uint8_t *ws;               // frame workspace base
   size_t ws_stride;
   size_t lm_off[FL_MAX_MODALITIES];
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanArgs a)
   const int item = __builtin_amdgcn_readfirstlane((q % a.bpf) * 4 + wave);
   if (item >= a.n_pyr * a.nchunks) return;
   const int g = item / a.nchunks, chunk = item - g * a.nchunks;
+  if (!a.enabled[g]) return;                             // wave-uniform: matchClass is not called for this class
   uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
   const int j0 = chunk * 1024 + lane * 16;
 
@@ -635,6 +637,7 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     ScanArgs a;
     a.hdr = det->d_scan_hdr;
     a.offs = det->d_scan_off;
+    a.enabled = det->d_pyr_enabled;
     a.ws = det->d_ws;
     a.ws_stride = det->ws_stride;
     for (int m = 0; m < FL_MAX_MODALITIES; ++m) a.lm_off[m] = g.lm_off[m < M ? m : 0];

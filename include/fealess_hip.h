@@ -135,6 +135,10 @@ int  fl_detector_set_model_depths(fl_detector *det, int class_idx, int first, in
  * flattened feature tables and allocates every per-frame workspace in HBM.  max_candidates is
  * the per-frame capacity of the candidate / match buffers (0 = default 65536). */
 int  fl_detector_finalize(fl_detector *det, int w0, int h0, int max_batch, int max_candidates);
+/* Detector::match's `class_ids` argument (linemod.hpp:319-327, linemod.cpp:1418-1434): n = 0 matches every
+ * class (the default, and what Recognition passes); otherwise only the listed classes that exist.
+ * Sticky until changed; may be called before or after fl_detector_finalize. */
+int  fl_detector_set_class_filter(fl_detector *det, const char *const *class_ids, int n);
 int  fl_detector_num_templates(const fl_detector *det);     /* Detector::numTemplates() :1652 */
 int  fl_detector_num_classes(const fl_detector *det);
 

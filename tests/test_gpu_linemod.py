@@ -84,6 +84,20 @@ def test_match_single_modality_and_multi_class(ctx, oracle):
     exp, n_exp = oracle.match_quantized(qs, w0, h0, T, sorted(banks, key=lambda b: b.class_id), 65.0)
     assert n_exp > 0 and n_got == n_exp
     _assert_matches_equal(got, exp)
+    # class_ids filter of Detector::match (linemod.cpp:1418-1434): only the listed classes that exist are matched;
+    # class_idx stays the index in the detector's sorted class map
+    srt = sorted(banks, key=lambda b: b.class_id)
+    det.set_class_filter(["mid", "nope", "mid"])
+    got_f, n_f = det.match_quantized(qs, 65.0)
+    keep = exp[exp["class_idx"] == [b.class_id for b in srt].index("mid")]
+    assert 0 < n_f == len(keep) < n_exp
+    _assert_matches_equal(got_f, keep)
+    det.set_class_filter(["nope"])
+    assert det.match_quantized(qs, 65.0)[1] == 0
+    det.set_class_filter([])                                   # back to all classes
+    got_a, n_a = det.match_quantized(qs, 65.0)
+    assert n_a == n_exp
+    _assert_matches_equal(got_a, exp)
     det.close()
 
 
