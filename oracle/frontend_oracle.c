@@ -227,8 +227,8 @@ static inline void accum_bilateral(long delta, long i, long j, long *A, long *b,
 void orc_quantized_normals(const uint16_t *depth, int w, int h, int distance_threshold,
                            int difference_threshold, uint8_t *dst)
 {
-  static uint8_t lut[8000];
-  static int lut_ready = 0;
+  static __thread uint8_t lut[8000];
+  static __thread int lut_ready = 0;
   if (!lut_ready) { orc_normal_lut(lut); lut_ready = 1; }
   size_t n = (size_t)w * h;
   uint8_t *tmp = (uint8_t *)calloc(n, 1);

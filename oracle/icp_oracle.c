@@ -158,8 +158,8 @@ static void nn_brute(const float *ref, int n_ref, const float *q, int *idx, floa
 /* kd-tree with leaf size 15 (KDTreeSingleIndexParams(15), ICP.cpp:658), exact search */
 typedef struct { int left, right, begin, end; float lo[3], hi[3]; } kd_node;
 typedef struct { kd_node *nodes; int n_nodes, cap; int *perm; const float *pts; } kd_tree;
-static const float *g_sort_pts;
-static int g_sort_dim;
+static __thread const float *g_sort_pts;   /* thread-local: bench.py times the oracle on several host threads */
+static __thread int g_sort_dim;
 static int cmp_dim(const void *a, const void *b)
 {
   float x = g_sort_pts[3 * *(const int *)a + g_sort_dim], y = g_sort_pts[3 * *(const int *)b + g_sort_dim];
