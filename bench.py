@@ -120,7 +120,7 @@ def cpu_baseline(args, bank, scenes):
     # (ctypes releases the GIL during the call; the oracle keeps no shared mutable state)
     import concurrent.futures as cf
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
+    cores = max(1, min(cores, 16))                                        # the CPU share of a one-GPU box
     per_thread = max(1, int(round(n / el * args.cpu_seconds / 2)))       # about cpu_seconds / 2 of work per thread
 
     def work(k):
