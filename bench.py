@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (implies a non-RCCL backend)")
     return ap.parse_args()
 
 
@@ -148,7 +151,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            local_rank = 0
+            dist.init_process_group("gloo" if args.dist_backend == "nccl" else args.dist_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
     from fealess_amd import api
