@@ -28,7 +28,7 @@
 #include <string.h>
 
 #define ICP_BS 256               // threads per frame workgroup = rows per LDS tile
-#if defined(FL_ICP_DEBUG) || defined(FL_ICP_PHASES)
+#ifdef FL_ICP_PHASES
 #define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
 #else
 #define TSTAMP(k) do { } while (0)
@@ -120,12 +120,6 @@ struct IcpShared {
   alignas(16) float dtile[2][ICP_BS];
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast;
-#endif
-#ifdef FL_ICP_DEBUG
-  int dbg[8];
-  long long tacc[8], tlast;
-  long long ta1[24];
-  int cells_it[24], wmax_it[24];
 #endif
 };
 
@@ -722,11 +716,6 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     for (int i = 0; i < 16; ++i) S.tacc[i] = 0;
     S.tlast = clock64();
 #endif
-#ifdef FL_ICP_DEBUG
-    for (int i = 0; i < 8; ++i) { S.dbg[i] = 0; S.tacc[i] = 0; }
-    for (int i = 0; i < 24; ++i) { S.ta1[i] = 0; S.cells_it[i] = 0; S.wmax_it[i] = 0; }
-    S.tlast = clock64();
-#endif
   }
   __syncthreads();
   if (n_model < 3 || n_ref < 3 || n_ref < n_model) {    // :633-638 (n_ref < n_model: reference reads OOB)
@@ -774,9 +763,6 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.  Every load
       // ahead of the search is coalesced and the next query's are issued before this query's search.
       const float r_thr = uniform_f(sqrtf(thr));
-#ifdef FL_ICP_DEBUG
-      int dbg_area = 0;
-#endif
       const NnGrid G = nn_grid(S);
       int i = threadIdx.x;
       float qx = 0.f, qy = 0.f, qz = 0.f, qb = 0.f;
@@ -788,9 +774,6 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
         float d = NAN;
         if (nn_ranges(G, qx, qy, qz, thr, r_thr, qb, &cx0, &cx1, &cy0, &cy1))
           nn_search_global(G, sref, cell_start, qx, qy, qz, cx0, cx1, cy0, cy1, &j, &d);
-#ifdef FL_ICP_DEBUG
-        dbg_area += (cx1 - cx0 + 1) * (cy1 - cy0 + 1);   // per-lane, reduced once after the loop
-#endif
         const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
         if (keep) ++kept;
         nn[i] = keep ? j : -1;
@@ -807,10 +790,6 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
         qx = nqx; qy = nqy; qz = nqz; qb = nqb;
       }
       __syncthreads();                                   // nn[] complete
-#ifdef FL_ICP_DEBUG
-      atomicAdd(&S.dbg[3], dbg_area); atomicAdd(&S.cells_it[iter < 24 ? iter : 23], dbg_area);
-      if (threadIdx.x == 0) { S.dbg[4] += n_model; S.ta1[iter < 24 ? iter : 23] += clock64() - S.tlast; }
-#endif
       TSTAMP(2);
     }
     // Phase A2 (iteration 1: the only phase): rows in index order.  Parity mode: waves 1-3 write
@@ -963,13 +942,6 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     }
     __syncthreads();
   }
-#ifdef FL_ICP_DEBUG
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    for (int it = 2; it < 22; ++it)
-      printf("  it %d A1 cycles %lld cells/query %.1f wave-max cells %.1f\n", it, S.ta1[it], (float)S.cells_it[it] / n_model,
-             (float)S.wmax_it[it] / ((n_model + 63) / 64));
-  if (threadIdx.x == 0 && blockIdx.x == 0) printf("icp dbg: (unused %d %d) cells/query %.1f queries %d GX %d GY %d n %d | cycles grid %lld qorder %lld A1 %lld A2 %lld svd %lld B %lld | stage %lld search %lld | cands %d rowsteps %d wave-iters %d\n", S.dbg[0], S.dbg[1], S.dbg[4] ? (float)S.dbg[3] / S.dbg[4] : 0.f, S.dbg[4], S.GX, S.GY, n_ref, S.tacc[0], S.tacc[1], S.tacc[2], S.tacc[3], S.tacc[4], S.tacc[5], S.tacc[6], S.tacc[7], S.dbg[5], S.dbg[6], S.dbg[7]);
-#endif
   if (threadIdx.x == 0) {
     for (int i = 0; i < 9; ++i) res->R[i] = S.R[i];
     for (int i = 0; i < 3; ++i) res->T[i] = S.T[i];

@@ -388,14 +388,7 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
   const int row = lane >> 2, col4 = (lane & 3) * 4;
   const int T = a.T, W = a.W;
   const int border = 8 * T, offset = T / 2 + (T % 2 - 1);
-#ifdef FL_REFINE_DEBUG
-  long long t_start = clock64();
-  int n_done = 0;
-#endif
   for (int ci = blockIdx.x * 4 + wave; ci < n; ci += gridDim.x * 4) {
-#ifdef FL_REFINE_DEBUG
-    ++n_done;
-#endif
     FlCand cd = cand[ci];
     const int g = __builtin_amdgcn_readfirstlane(cd.g);
     if (g < 0) continue;
@@ -502,9 +495,6 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
       cand[ci] = cd;
     }
   }
-#ifdef FL_REFINE_DEBUG
-  if (blockIdx.y == 0 && lane == 0) printf("refine dbg: block %d wave %d n %d done %d cycles %lld\n", blockIdx.x, wave, n, n_done, clock64() - t_start);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
