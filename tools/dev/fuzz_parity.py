@@ -1,0 +1,89 @@
+"""dev: randomized GPU-vs-oracle differential run (longer than the test-suite budget).
+usage (GPU box): python tools/dev/fuzz_parity.py [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401  (HIP runtime first)
+import oracle_py as O
+from fealess_amd import api, synth, _lib as L
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+ctx = api.Context(0)
+t0 = time.time()
+stats = dict(icp=0, frontend=0, recognition=0, linemod=0, fail=0)
+def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
+seed = 1000
+while time.time() - t0 < budget:
+    seed += 1
+    rng = np.random.default_rng(seed)
+    kind = seed % 4 if len(sys.argv) < 3 else int(sys.argv[2])
+    try:
+        if kind == 0:      # ICP on random paired clouds of random size / misalignment / noise / invalid points
+            n = int(rng.integers(3, 9000))
+            R, t = synth.object_pose(tz=float(rng.uniform(500, 800)))
+            depth, _, mask = synth.render(640, 480, R, t, seed=seed, noise=True, background=False)
+            ys, xs = np.nonzero(mask)
+            sel = np.sort(rng.choice(len(ys), size=min(n, len(ys)), replace=False))
+            z = depth[ys[sel], xs[sel]].astype(np.float32)
+            ref = np.stack([(xs[sel] - 320.0) / 608.0 * z, (ys[sel] - 240.0) / 608.0 * z, z], 1).astype(np.float32)
+            dR = synth.rot_z(rng.uniform(-.05, .05)) @ synth.rot_x(rng.uniform(-.04, .04)) @ synth.rot_y(rng.uniform(-.04, .04))
+            c = ref.mean(0)
+            model = ((ref - c) @ dR.T + c + rng.uniform(-4, 4, 3)).astype(np.float32)
+            model += rng.normal(0, rng.uniform(0, 0.5), model.shape).astype(np.float32)
+            m = int(rng.integers(max(3, len(model) // 2), len(model) + 1)) if len(model) > 6 else len(model)
+            model = model[:m]
+            for k in rng.integers(0, len(model), size=int(rng.integers(0, 4))):
+                model[k] = (1.0, 2.0, 950.0) if rng.random() < .5 else (np.nan, np.nan, np.nan)
+            it = int(rng.integers(1, 12))
+            a = (it, float(rng.choice([0.0, 0.3])), float(rng.choice([-3e38, 0.01])))
+            got = ctx.icp_cloud_to_cloud_ex(ref, model, *a, L.FL_ICP_PARITY)
+            exp = O.icp(ref, model, *a, accum64=False, use_kdtree=True)
+            ok = got["iters"] == exp["iters"] and got["n_corr_last"] == exp["n_corr_last"] and \
+                np.array_equal(bits(got["R"]), bits(exp["R"])) and np.array_equal(bits(got["T"]), bits(exp["T"]))
+            stats["icp"] += 1
+        elif kind == 1:    # front-end on random size images
+            w, h = int(rng.integers(16, 400)), int(rng.integers(16, 300))
+            bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            if rng.random() < .5: bgr = (bgr // 32 * 32).astype(np.uint8)
+            dep = (600 + rng.integers(0, int(rng.integers(2, 400)), (h, w))).astype(np.uint16)
+            dep[rng.random((h, w)) < 0.02] = 0
+            ok = np.array_equal(ctx.quantized_orientations(bgr, 10.0), O.quantized_orientations(bgr, 10.0)) and \
+                np.array_equal(ctx.quantized_normals(dep), O.quantized_normals(dep)) and \
+                (w < 2 or h < 2 or np.array_equal(ctx.pyrdown_bgr(bgr), O.pyrdown_bgr(bgr)))
+            dw, dh = int(rng.integers(8, 400)), int(rng.integers(8, 300))
+            ok = ok and np.array_equal(ctx.resize_linear(bgr, dw, dh), O.resize_linear_u8(bgr, dw, dh)) and \
+                np.array_equal(ctx.resize_linear(dep, dw, dh), O.resize_linear_u16(dep, dw, dh))
+            stats["frontend"] += 1
+        elif kind == 2:    # whole Recognition on a random synthetic scene
+            sc = synth.recognition_scene(lambda b, d, l: O.quantize_pyramid(b, d, l), levels=2, seed=seed, n_views=3, n_random=10)
+            det = api.Detector(ctx, 2, [5, 8]); det.add_class(sc["bank"]); det.finalize(640, 480)
+            it = int(rng.integers(1, 12))
+            r = det.recognize_batch([sc["bgr"]], [sc["depth"]], sc["K"], 70.0, it, 0.3, 0.01)[0]
+            e = O.recognition(sc["bgr"], sc["depth"], sc["K"], [5, 8], sc["bank"], 70.0, it, 0.3, 0.01)
+            ok = r["found"] == e["found"] and r["n_matches"] == e["n_matches"] and (not e["found"] or np.array_equal(bits(r["pose"]), bits(e["pose"])))
+            det.close()
+            stats["recognition"] += 1
+        else:              # LINEMOD on random quantized pyramids / banks
+            levels = int(rng.integers(1, 4))
+            T = [[8], [4, 8], [4, 8, 4]][levels - 1]
+            w0, h0 = [(160, 128), (320, 160), (320, 256)][levels - 1]
+            dens = float(rng.uniform(0.02, 0.08))
+            qs = [synth.random_quantized(rng, w0 >> l, h0 >> l, dens) for l in range(levels) for _ in range(2)]
+            bank = synth.make_bank("o", int(rng.integers(1, 40)), levels, 2, w0, h0, seed=seed, qs=qs, planted_frac=0.3, bbox=64)
+            det = api.Detector(ctx, 2, T); det.add_class(bank); det.finalize(w0, h0)
+            thr = float(rng.uniform(50, 90))
+            got, ng = det.match_quantized(qs, thr)
+            exp, ne = O.match_quantized(qs, w0, h0, T, [bank], thr)
+            ok = ng == ne and all(np.array_equal(got[k], exp[k]) for k in ("x", "y", "class_idx", "template_id")) and \
+                np.array_equal(got["similarity"].view(np.uint32), exp["similarity"].view(np.uint32))
+            det.close()
+            stats["linemod"] += 1
+    except Exception as ex:      # noqa: BLE001
+        ok = False
+        print("seed", seed, "kind", kind, "raised", repr(ex)[:300])
+    if not ok:
+        stats["fail"] += 1
+        print("MISMATCH seed", seed, "kind", kind)
+print("fuzz done:", stats, "in %.0f s" % (time.time() - t0))
+sys.exit(1 if stats["fail"] else 0)
