@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--templates", type=int, default=360)
     ap.add_argument("--levels", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=1280, help="frames per step per GPU (1280 = 5 ICP workgroups on each of the 256 CUs)")
     ap.add_argument("--icp-iters", type=int, default=20)
     ap.add_argument("--icp-mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
@@ -221,12 +221,12 @@ def main():
     traffic = None
     traffic_detail = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_b1024.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_b1280.json")))
         if pm["batch"] == B and pm["templates"] == bank.n_pyramids and args.icp_mode == "parity":
             kd = pm["kernels"][dom if dom != "k_icp_pipeline" else "k_icp_pipeline<0>"]
             traffic = (kd["FETCH_SIZE"] + kd["WRITE_SIZE"]) * 1024.0          # bytes per launch, raw counters
             traffic_detail = dict(fetch_bytes=kd["FETCH_SIZE"] * 1024, write_bytes=kd["WRITE_SIZE"] * 1024,
-                                  source="profiles/r01_final_pmc_b1024.json",
+                                  source="profiles/r01_final_pmc_b1280.json",
                                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; gfx950 FETCH_SIZE "
                                        "under-counts wide coalesced reads by up to 2x (this kernel's reads are mostly "
                                        "4-16 B gathers: uncalibrated), so true HBM reads lie between 1x and 2x fetch_bytes")

@@ -34,10 +34,15 @@
 #define TSTAMP(k) do { } while (0)
 #endif
 #define ICP_MAX_THREADS ICP_BS
+#ifndef FL_ICP_WPE
+#define FL_ICP_WPE 5               // waves per SIMD the recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96):
+                                  // measured +4 % frames/s at 5 workgroups per CU (LDS: 5 x 27 KB)
+#endif
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
-#define ICP_TS (ICP_BS + 4)         // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4 keeps
+#define ICP_TQ (ICP_BS - 64)        // rows per LDS tile: virtual wave 0 chains, the other three produce one row per thread
+#define ICP_TS (ICP_TQ + 4)         // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4 keeps
                                   // the 16 chain lanes of a b128 read on distinct bank groups
 
 // HBM layout of one frame's ICP workspace (n = capacity in points):
@@ -116,8 +121,8 @@ struct IcpShared {
   // double-buffered LDS tiles feeding the sequential float32 chains (FL_ICP_PARITY):
   // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords, pad) of row r of tile b;
   // +1 column of padding puts the 16 chain lanes on 16 different banks
-  alignas(16) float prod[2][16][ICP_TS];
-  alignas(16) float dtile[2][ICP_BS];
+  alignas(16) float prod[2][15][ICP_TS];
+  alignas(16) float dtile[2][ICP_TQ];
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast;
 #endif
@@ -1016,7 +1021,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_icp_pipeline(IcpArgs a)
+__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(FL_ICP_WPE, FL_ICP_WPE))) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;

@@ -7,7 +7,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B=${B:-1024}
+B=${B:-1280}
 CMD="python3 bench.py --steps 5 --warmup 2 --batch $B --no-cpu-baseline"
 out=gpurun_out/prof_final
 rm -rf $out gpurun_out/pmc_final_*

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
 out = os.path.join(ROOT, "profiles")
 src = os.path.join(ROOT, "gpurun_out")
 
