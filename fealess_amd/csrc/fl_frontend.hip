@@ -90,7 +90,10 @@ __device__ __forceinline__ void cq_hrow(const uint8_t *__restrict__ src, int w, 
   h3[2] = a2;
 }
 
-__global__ __launch_bounds__(256) void k_color_quantize(const uint8_t *__restrict__ bgr, size_t in_stride,
+#ifndef FL_CQ_WPE
+#define FL_CQ_WPE 6              // 80 VGPRs, no spills: 6 waves per SIMD (measured: 5 -> 6 gives -2 % front-end time, 7/8 spill)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, FL_CQ_WPE))) void k_color_quantize(const uint8_t *__restrict__ bgr, size_t in_stride,
                                                         uint8_t *__restrict__ dst, size_t out_stride, int w, int h,
                                                         float threshold_sq, int nstrips, int nchunks)
 {

@@ -264,7 +264,10 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *p)
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_scan(ScanArgs a)
+#ifndef FL_SCAN_WPE
+#define FL_SCAN_WPE 4             // measured: 5 or 6 waves per SIMD spill and are 25-55 % slower
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE, FL_SCAN_WPE))) void k_scan(ScanArgs a)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs, each with its own

@@ -1,9 +1,9 @@
 #!/bin/bash
-# dev only (tools/dev/README.md): build fl_icp.hip with different -D flags on the GPU box and bench each (usage: dev_variants.sh "flags1" "flags2" ...)
+# dev only (tools/dev/README.md): build the library with different -D flags on the GPU box and bench each (usage: dev_variants.sh "flags1" "flags2" ...)
 cd fealess_amd/csrc
 BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize"
 for v in "$@"; do
-  rm -f fl_icp.o
+  rm -f *.o
   make -s CXXFLAGS="$BASE $v" 2>&1 | grep error
-  (cd ../.. && timeout -k 10 200 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --batch ${B:-1024} 2>&1 | grep -o "  it .*\|  deferred.*\|icp phase.*\|icp dbg.*\|\"value[^,]*\|icp_ms[^,]*\|detections[^,]*" | sed "s/^/[$v] /" | cut -c1-400; echo)
+  (cd ../.. && timeout -k 10 200 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --batch ${B:-1280} 2>&1 | grep -o "icp phase.*\|\"value[^,]*\|stage_ms_last_step[^}]*" | sed "s/^/[$v] /" | cut -c1-400; echo)
 done
