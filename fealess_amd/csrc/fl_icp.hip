@@ -27,7 +27,10 @@
 #include <math.h>
 #include <string.h>
 
-#define ICP_BS 256               // threads per frame workgroup = rows per LDS tile
+#ifndef FL_ICP_BS
+#define FL_ICP_BS 256
+#endif
+#define ICP_BS FL_ICP_BS         // threads per frame workgroup (64 chain lanes + ICP_BS - 64 producers in parity mode)
 #ifdef FL_ICP_PHASES
 #define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
 #else
