@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfealess_hip.so")
 
 FL_OK = 0
-FL_ERR_INVALID, FL_ERR_HIP, FL_ERR_ASSERT, FL_ERR_OVERFLOW, FL_ERR_NO_DEVICE, FL_ERR_STATE = -1, -2, -3, -4, -5, -6
+FL_ERR_INVALID, FL_ERR_HIP, FL_ERR_ASSERT, FL_ERR_OVERFLOW, FL_ERR_NO_DEVICE, FL_ERR_STATE, FL_ERR_NO_TEMPLATE = -1, -2, -3, -4, -5, -6, -7
 FL_MEM_HOST, FL_MEM_DEVICE = 0, 1
 FL_ICP_PARITY, FL_ICP_FAST = 0, 1
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     "fl_quantized_orientations": (_I, [_P, _P, _I, _I, _F, _P, _I]),
     "fl_quantized_normals": (_I, [_P, _P, _I, _I, _I, _I, _P, _I]),
     "fl_pyrdown_bgr": (_I, [_P, _P, _I, _I, _P, _I]),
+    "fl_extract_template_pyramid": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, C.POINTER(_I)]),
     "fl_resize_linear_bgr8": (_I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     "fl_resize_linear_u16": (_I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     "fl_lm_label_stride": (C.c_size_t, [_I, _I, _I]),

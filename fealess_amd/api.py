@@ -83,6 +83,31 @@ class Context:
             self.check(self.lib.fl_resize_linear_bgr8(self.h, _ptr(a), a.shape[1], a.shape[0], _ptr(out), dw, dh, L.FL_MEM_HOST))
         return out
 
+    def extract_template_pyramid(self, bgr, depth, mask, levels):
+        """Detector::addTemplate's extraction (linemod.cpp:1579-1615), default modalities.  Returns (templates, bb):
+        templates = levels * 2 dicts ordered [l * 2 + m], ready for TemplateBank.add_pyramid, bb = (x, y, w, h);
+        None where the reference returns -1 (too few candidate features)."""
+        from .bank import FEATURE_DTYPE, TEMPLATE_DTYPE
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        h, w = depth.shape
+        t = np.zeros(levels * 2, TEMPLATE_DTYPE)
+        f = np.zeros(levels * 2 * 63, FEATURE_DTYPE)
+        bb = (C.c_int * 4)()
+        rc = self.lib.fl_extract_template_pyramid(self.h, _ptr(bgr), _ptr(depth), None if mk is None else _ptr(mk), w, h, levels,
+                                                  L.FL_MEM_HOST, _ptr(t), _ptr(f), bb)
+        if rc == L.FL_ERR_NO_TEMPLATE:
+            return None
+        self.check(rc)
+        out = []
+        for k in range(levels * 2):
+            fb, fc = int(t[k]["feat_begin"]), int(t[k]["feat_count"])
+            feats = np.stack([f["x"][fb:fb + fc], f["y"][fb:fb + fc], f["label"][fb:fb + fc]], axis=1).astype(np.int32)
+            out.append(dict(width=int(t[k]["width"]), height=int(t[k]["height"]), offset_x=int(t[k]["offset_x"]),
+                            offset_y=int(t[k]["offset_y"]), pyramid_level=int(t[k]["pyramid_level"]), features=feats))
+        return out, tuple(bb)
+
     def build_linear_memories(self, quantized, T):
         q = np.ascontiguousarray(quantized, np.uint8)
         h, w = q.shape

@@ -95,7 +95,8 @@ __device__ __forceinline__ void cq_hrow(const uint8_t *__restrict__ src, int w, 
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, FL_CQ_WPE))) void k_color_quantize(const uint8_t *__restrict__ bgr, size_t in_stride,
                                                         uint8_t *__restrict__ dst, size_t out_stride, int w, int h,
-                                                        float threshold_sq, int nstrips, int nchunks)
+                                                        float threshold_sq, int nstrips, int nchunks,
+                                                        float *__restrict__ mag_out)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave;
@@ -190,6 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
         if (maj) res = (uint8_t)(1u << ((__ffs((int)maj) - 4) >> 2));
       }
       out[(size_t)yo * w + x] = res;
+      // template extraction also wants the squared magnitude image (linemod.cpp:461-513); one frame only
+      if (mag_out) mag_out[(size_t)yo * w + x] = Mg[1];
     }
   }
 }
@@ -197,10 +200,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
 int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst,
                                      size_t out_stride, int n_frames, int w, int h, float weak_threshold)
 {
+  return fl_launch_quantized_orientations_mag(ctx, bgr, in_stride, dst, out_stride, n_frames, w, h, weak_threshold, nullptr);
+}
+
+int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst,
+                                         size_t out_stride, int n_frames, int w, int h, float weak_threshold, float *mag_out)
+{
   const int nstrips = (w + CQ_COLS - 1) / CQ_COLS, nchunks = (h + CQ_CH - 1) / CQ_CH;
   dim3 grid((nstrips * nchunks + 3) / 4, 1, n_frames);
   hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, ctx->stream, bgr, in_stride, dst, out_stride, w, h,
-                     weak_threshold * weak_threshold, nstrips, nchunks);
+                     weak_threshold * weak_threshold, nstrips, nchunks, mag_out);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }

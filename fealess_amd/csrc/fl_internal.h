@@ -154,6 +154,8 @@ int fl_launch_pyrdown_bgr(fl_context *ctx, const uint8_t *src, size_t in_stride,
                           size_t out_stride, int n_frames, int w, int h);
 int fl_launch_resize_nn_half(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst,
                              size_t out_stride, int n_frames, int w, int h);
+int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst, size_t out_stride,
+                                         int n_frames, int w, int h, float weak_threshold, float *mag_out);
 int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_t bgr_stride,
                        const uint16_t *depth, size_t depth_stride);
 // icp

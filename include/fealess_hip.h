@@ -36,7 +36,8 @@ typedef enum {
   FL_ERR_ASSERT = -3,    /* the reference would hit a CV_Assert / cv::Exception here            */
   FL_ERR_OVERFLOW = -4,  /* a fixed-capacity device buffer overflowed (see fl_detector_limits)  */
   FL_ERR_NO_DEVICE = -5,
-  FL_ERR_STATE = -6      /* call order violated (e.g. matching before fl_detector_finalize)     */
+  FL_ERR_STATE = -6,     /* call order violated (e.g. matching before fl_detector_finalize)     */
+  FL_ERR_NO_TEMPLATE = -7 /* fl_extract_template_pyramid: too few candidate features (addTemplate's -1) */
 } fl_status;
 
 typedef enum { FL_MEM_HOST = 0, FL_MEM_DEVICE = 1 } fl_mem;
@@ -151,6 +152,14 @@ int  fl_quantized_normals(fl_context *ctx, const uint16_t *depth, int w, int h,
                           int distance_threshold, int difference_threshold, uint8_t *dst, int mem);
 /* cv::pyrDown on the colour image (linemod.cpp:443): w*h*3 -> (w/2)*(h/2)*3 */
 int  fl_pyrdown_bgr(fl_context *ctx, const uint8_t *src, int w, int h, uint8_t *dst, int mem);
+/* Detector::addTemplate (linemod.cpp:1579-1615) for the two default modalities ColorGradient(10, 63, 55) and
+ * DepthNormal(2000, 50, 63, 2): quantized pyramids, extractTemplate per level and modality (:461-513, :747-825),
+ * selectScatteredFeatures (:135-164), cropTemplates (:52-96).  mask: object mask (w0*h0 u8) or NULL.
+ * Out (host): templates[levels * 2] ordered [l * 2 + m] with feat_begin = 63 * (l * 2 + m), features[levels * 2 * 63]
+ * (template-relative after the crop), bb = {x, y, width, height} (may be NULL).  Returns FL_ERR_NO_TEMPLATE where
+ * the reference returns -1.  The caller appends the pyramid to a class with fl_detector_add_class. */
+int  fl_extract_template_pyramid(fl_context *ctx, const uint8_t *bgr, const uint16_t *depth, const uint8_t *mask, int w0,
+                                 int h0, int levels, int mem, fl_template *templates, fl_feature *features, int bb[4]);
 /* cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_LINEAR) as PrepareInputData applies it to frames
  * that are not 640 wide (obj_reco_lmicp.cpp:39-45, 229-249: TImage2Mat(..., true)); BGR8 and u16 */
 int  fl_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, int mem);

@@ -109,6 +109,19 @@ int  orc_match_images_masked(const uint8_t *bgr, const uint16_t *depth, int w0, 
                              const uint8_t *mask_color, const uint8_t *mask_depth,
                              orc_match *out, int cap, int *n_total, uint8_t *quantized_out);
 
+/* ---- template extraction (extract_oracle.c) ------------------------------ */
+void orc_erode_rect(const uint8_t *src, int w, int h, int iterations, uint8_t *dst);            /* cv::erode 3x3 rect */
+void orc_distance_transform_c3(const uint8_t *src, int w, int h, float *dst);                   /* DIST_C, 3x3 */
+int  orc_extract_template_color(const uint8_t *quantized, const float *magnitude, const uint8_t *mask, int w, int h,
+                                float strong_threshold, int num_features, orc_feature *out);    /* linemod.cpp:461-513 */
+int  orc_extract_template_depth(const uint8_t *normal, const uint8_t *mask, int w, int h, int extract_threshold,
+                                int num_features, orc_feature *out);                            /* linemod.cpp:747-825 */
+void orc_crop_templates(orc_template *t, int n, orc_feature *feats, int bb[4]);                 /* linemod.cpp:52-96 */
+/* Detector::addTemplate (linemod.cpp:1579-1615), default modalities; templates[levels*2] ordered [l*2+m], feature
+ * slot of template k = feats + 63*k; returns 0 / -1 */
+int  orc_add_template(const uint8_t *bgr, const uint16_t *depth, const uint8_t *mask, int w0, int h0, int levels,
+                      orc_template *templates, orc_feature *feats, int bb[4]);
+
 /* ---- back-projection + ICP ------------------------------------------------------------- */
 /* cup_d2pc::depthTo3d u16 path (depth_to_3d.cpp:99-137,190-221,244-269): out is w*h*3 f32, metres */
 void orc_depth_to_3d(const uint16_t *depth, int w, int h, double fx, double fy, double cx,

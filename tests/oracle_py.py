@@ -186,6 +186,68 @@ def resize_linear_u16(img, dw, dh):
     return out
 
 
+def erode_rect(mask, iterations):
+    m = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros_like(m)
+    lib().orc_erode_rect(_p(m), m.shape[1], m.shape[0], iterations, _p(out))
+    return out
+
+
+def distance_transform_c3(img):
+    m = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(m.shape, np.float32)
+    lib().orc_distance_transform_c3(_p(m), m.shape[1], m.shape[0], _p(out))
+    return out
+
+
+FEAT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("label", "<i4")])
+TEMPL_DTYPE = np.dtype([("width", "<i4"), ("height", "<i4"), ("offset_x", "<i4"), ("offset_y", "<i4"),
+                        ("pyramid_level", "<i4"), ("feat_begin", "<i4"), ("feat_count", "<i4")])
+
+
+def extract_template_color(quantized, magnitude, mask, strong_threshold, num_features):
+    q = np.ascontiguousarray(quantized, np.uint8)
+    mg = np.ascontiguousarray(magnitude, np.float32)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros(num_features, FEAT_DTYPE)
+    ok = lib().orc_extract_template_color(_p(q), _p(mg), None if mk is None else _p(mk), q.shape[1], q.shape[0],
+                                          C.c_float(strong_threshold), num_features, _p(out))
+    return out if ok else None
+
+
+def extract_template_depth(normal, mask, extract_threshold, num_features):
+    q = np.ascontiguousarray(normal, np.uint8)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros(num_features, FEAT_DTYPE)
+    ok = lib().orc_extract_template_depth(_p(q), None if mk is None else _p(mk), q.shape[1], q.shape[0], extract_threshold,
+                                          num_features, _p(out))
+    return out if ok else None
+
+
+def quantized_orientations_mag(bgr, weak_threshold=10.0):
+    b = np.ascontiguousarray(bgr, np.uint8)
+    out = np.zeros(b.shape[:2], np.uint8)
+    mag = np.zeros(b.shape[:2], np.float32)
+    lib().orc_quantized_orientations(_p(b), b.shape[1], b.shape[0], C.c_float(weak_threshold), _p(out), _p(mag))
+    return out, mag
+
+
+def add_template(bgr, depth, mask, levels):
+    """Detector::addTemplate: returns (templates[levels*2] TEMPL_DTYPE, features list per template, bb) or None."""
+    b = np.ascontiguousarray(bgr, np.uint8)
+    d = np.ascontiguousarray(depth, np.uint16)
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    h, w = d.shape
+    t = np.zeros(levels * 2, TEMPL_DTYPE)
+    f = np.zeros(levels * 2 * 63, FEAT_DTYPE)
+    bb = (C.c_int * 4)()
+    rc = lib().orc_add_template(_p(b), _p(d), None if mk is None else _p(mk), w, h, levels, _p(t), _p(f), bb)
+    if rc:
+        return None
+    feats = [f[t[k]["feat_begin"]:t[k]["feat_begin"] + t[k]["feat_count"]].copy() for k in range(levels * 2)]
+    return t, feats, tuple(bb)
+
+
 def quantize_pyramid(bgr, depth, levels):
     """The two default modalities' quantized images per level, order [l*2 + m]."""
     out = []

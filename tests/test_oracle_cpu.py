@@ -327,3 +327,61 @@ def test_resize_linear_properties(oracle):
     assert np.abs(r8[5, 1:-1, 0].astype(float) - x[1:-1] * 3).max() < 1.0   # 11-bit taps, truncating shifts
     up = oracle.resize_linear_u8(a, 256, 192)                     # enlarging: borders replicate (sx < 0 -> 0, fx = 0)
     assert np.array_equal(up[0, 0], a[0, 0]) and np.array_equal(up[-1, -1], a[-1, -1])
+
+
+def test_erode_and_distance_transform_pinned_against_scipy(oracle):
+    """The two OpenCV calls of extractTemplate, restated in oracle/extract_oracle.c, against an independent
+    implementation: cv::erode (3x3 rectangle, n iterations, BORDER_REPLICATE) = (2n+1)^2 minimum filter with edge
+    replication; cv::distanceTransform(DIST_C, 3) = exact chessboard distance to the nearest zero pixel."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(0)
+    for shape, p in (((60, 80), 0.8), ((33, 47), 0.95), ((5, 7), 0.5)):
+        m = (rng.random(shape) < p).astype(np.uint8) * 255
+        for it in (1, 2):
+            assert np.array_equal(oracle.erode_rect(m, it), ndi.minimum_filter(m, size=2 * it + 1, mode="nearest"))
+        img = (rng.random(shape) < 0.97).astype(np.uint8) * 64
+        if img.all():
+            img[0, 0] = 0
+        assert np.array_equal(oracle.distance_transform_c3(img),
+                              ndi.distance_transform_cdt(img != 0, metric="chessboard").astype(np.float32))
+    assert (oracle.distance_transform_c3(np.full((5, 7), 3, np.uint8)) == 8192.0).all()   # no zero pixel: capped INIT_DIST0
+
+
+def test_extract_template_semantics(oracle):
+    """extractTemplate / selectScatteredFeatures / cropTemplates / addTemplate (linemod.cpp:52-164, 461-513, 747-825,
+    1579-1615): hand-checkable properties of the restatement."""
+    R, t = synth.object_pose(tz=650.0)
+    depth, bgr, mask = synth.render(640, 480, R, t, seed=3, noise=False, background=True)
+    m255 = (mask * 255).astype(np.uint8)
+    out = oracle.add_template(bgr, depth, m255, 2)
+    assert out is not None
+    tl, feats, bb = out
+    assert [len(f) for f in feats] == [63, 63, 31, 31] and bb[0] % 2 == 0 and bb[1] % 2 == 0
+    for k in range(4):
+        l = int(tl[k]["pyramid_level"])
+        assert l == k // 2 and tl[k]["width"] == bb[2] >> l and tl[k]["offset_x"] == bb[0] >> l
+        f = feats[k]
+        assert f["x"].min() >= 0 and f["y"].min() >= 0 and f["x"].max() <= tl[k]["width"] and (0 <= f["label"]).all() and (f["label"] < 8).all()
+        assert len({(int(a), int(b)) for a, b in zip(f["x"], f["y"])}) == len(f)        # scattered: no position twice
+    # colour features lie on the border of the mask (mask - erode(mask)), depth features inside the 5x5-eroded mask
+    q, mag = oracle.quantized_orientations_mag(bgr)
+    border = (m255 > 0) & (oracle.erode_rect(m255, 1) == 0)
+    f = feats[0]
+    ax, ay = f["x"] + tl[0]["offset_x"], f["y"] + tl[0]["offset_y"]
+    assert border[ay, ax].all() and (mag[ay, ax] > 55.0 ** 2).all() and np.array_equal(1 << f["label"], q[ay, ax])
+    f = feats[1]
+    ax, ay = f["x"] + tl[1]["offset_x"], f["y"] + tl[1]["offset_y"]
+    qn = oracle.quantized_normals(depth)
+    assert (oracle.erode_rect(m255, 2)[ay, ax] > 0).all() and np.array_equal(1 << f["label"], qn[ay, ax])
+    # the stand-alone entry point with a candidate set of exactly num_features returns them all (any order of choice)
+    qq = np.zeros((40, 40), np.uint8)
+    mg = np.zeros((40, 40), np.float32)
+    pts = [(3, 4), (20, 7), (35, 30), (9, 33)]
+    for i, (x, y) in enumerate(pts):
+        qq[y, x] = 1 << i
+        mg[y, x] = 4000.0 + i
+    got = oracle.extract_template_color(qq, mg, None, 55.0, 4)
+    assert got[0]["x"] == 9 and got[0]["label"] == 3                                  # highest score first
+    assert sorted((int(a), int(b)) for a, b in zip(got["x"], got["y"])) == sorted(pts)
+    assert oracle.extract_template_color(qq, mg, None, 55.0, 5) is None                # too few candidates
+    assert oracle.add_template(np.zeros((480, 640, 3), np.uint8), np.full((480, 640), 1000, np.uint16), None, 2) is None

@@ -11,13 +11,13 @@ from fealess_amd import api, synth, _lib as L
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 ctx = api.Context(0)
 t0 = time.time()
-stats = dict(icp=0, frontend=0, recognition=0, linemod=0, fail=0)
+stats = dict(icp=0, frontend=0, recognition=0, linemod=0, extract=0, fail=0)
 def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
 seed = 1000
 while time.time() - t0 < budget:
     seed += 1
     rng = np.random.default_rng(seed)
-    kind = seed % 4 if len(sys.argv) < 3 else int(sys.argv[2])
+    kind = seed % 5 if len(sys.argv) < 3 else int(sys.argv[2])
     try:
         if kind == 0:      # ICP on random paired clouds of random size / misalignment / noise / invalid points
             n = int(rng.integers(3, 9000))
@@ -64,6 +64,20 @@ while time.time() - t0 < budget:
             ok = r["found"] == e["found"] and r["n_matches"] == e["n_matches"] and (not e["found"] or np.array_equal(bits(r["pose"]), bits(e["pose"])))
             det.close()
             stats["recognition"] += 1
+        elif kind == 4:    # template extraction (addTemplate) on a random view, with / without mask, 1-3 levels
+            R, t = synth.object_pose(tx=float(rng.uniform(-60, 60)), ty=float(rng.uniform(-40, 40)), tz=float(rng.uniform(560, 760)),
+                                     yaw=float(rng.uniform(-0.5, 0.5)), tilt=float(rng.uniform(0.2, 0.5)), roll=float(rng.uniform(-0.2, 0.2)))
+            depth, bgr, mask = synth.render(640, 480, R, t, seed=seed, noise=bool(rng.integers(0, 2)), background=True)
+            mk = (mask * 255).astype(np.uint8) if rng.random() < 0.7 else None
+            lv = int(rng.integers(1, 4))
+            e = O.add_template(bgr, depth, mk, lv)
+            g = ctx.extract_template_pyramid(bgr, depth, mk, lv)
+            ok = (e is None) == (g is None)
+            if ok and e is not None:
+                ok = tuple(g[1]) == tuple(e[2]) and all(
+                    np.array_equal(g[0][k]["features"], np.stack([e[1][k]["x"], e[1][k]["y"], e[1][k]["label"]], 1)) and
+                    g[0][k]["width"] == int(e[0][k]["width"]) and g[0][k]["offset_y"] == int(e[0][k]["offset_y"]) for k in range(lv * 2))
+            stats["extract"] += 1
         else:              # LINEMOD on random quantized pyramids / banks
             levels = int(rng.integers(1, 4))
             T = [[8], [4, 8], [4, 8, 4]][levels - 1]
