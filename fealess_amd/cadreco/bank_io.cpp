@@ -7,6 +7,7 @@
 // sequences introduced by "-", flow sequences "[ ... ]" (possibly wrapped over several lines),
 // plain / quoted scalars.  The PNG reader handles non-interlaced 8/16-bit grayscale (zlib inflate
 // + the five scanline filters).
+#include <sys/stat.h>
 #include "fealess_cadreco.h"
 
 #include <zlib.h>
@@ -206,6 +207,128 @@ bool ReadLinemod(const std::string &filename, DetectorFile &out, std::string *er
       out.classes.push_back(oc);
     }
   if (!p.err.empty() && err) *err = p.err;
+  return true;
+}
+
+// ---- packed binary cache of a DetectorFile (parsing a 16000-template YAML takes seconds, the
+// cache is read with a handful of fread calls).  Little-endian, versioned, with the YAML's size and mtime so a stale
+// cache is ignored.  Layout: magic "FLBANK1\0", u64 yml_size, i64 yml_mtime, i32 levels, i32 nT, T[], i32 nmod,
+// {i32 len, bytes}[], i32 nclasses, per class {i32 len, id, i32 npyr, per pyramid {i32 npose, f32[], i32 ntempl,
+// per template {5 x i32, i32 nfeat, nfeat x 3 x i32}}}.
+namespace {
+struct BinW {
+  FILE *f;
+  bool ok = true;
+  void raw(const void *p, size_t n) { ok = ok && fwrite(p, 1, n, f) == n; }
+  void i32(int v) { raw(&v, 4); }
+  void str(const std::string &s) { i32((int)s.size()); raw(s.data(), s.size()); }
+};
+struct BinR {
+  FILE *f;
+  bool ok = true;
+  void raw(void *p, size_t n) { ok = ok && fread(p, 1, n, f) == n; }
+  int i32() { int v = 0; raw(&v, 4); return v; }
+  std::string str() { int n = i32(); std::string s; if (ok && n >= 0 && n < (1 << 20)) { s.resize((size_t)n); raw(&s[0], (size_t)n); } else ok = false; return s; }
+};
+const char kBankMagic[8] = {'F', 'L', 'B', 'A', 'N', 'K', '1', 0};
+}  // namespace
+
+bool WriteBankCache(const DetectorFile &det, const std::string &filename, unsigned long long yml_size, long long yml_mtime)
+{
+  FILE *f = fopen(filename.c_str(), "wb");
+  if (!f) return false;
+  BinW w{f};
+  w.raw(kBankMagic, 8);
+  w.raw(&yml_size, 8);
+  w.raw(&yml_mtime, 8);
+  w.i32(det.pyramid_levels);
+  w.i32((int)det.T.size());
+  for (int t : det.T) w.i32(t);
+  w.i32((int)det.modalities.size());
+  for (auto &m : det.modalities) w.str(m);
+  w.i32((int)det.classes.size());
+  for (auto &c : det.classes) {
+    w.str(c.class_id);
+    w.i32((int)c.template_pyramids.size());
+    for (size_t p = 0; p < c.template_pyramids.size(); ++p) {
+      const std::vector<float> &pose = p < c.poses.size() ? c.poses[p] : std::vector<float>();
+      w.i32((int)pose.size());
+      if (!pose.empty()) w.raw(pose.data(), pose.size() * 4);
+      w.i32((int)c.template_pyramids[p].size());
+      for (auto &t : c.template_pyramids[p]) {
+        const int hdr[6] = {t.width, t.height, t.offset_x, t.offset_y, t.pyramid_level, (int)t.features.size()};
+        w.raw(hdr, sizeof(hdr));
+        if (!t.features.empty()) w.raw(t.features.data(), t.features.size() * sizeof(Feature));
+      }
+    }
+  }
+  const bool ok = w.ok;
+  return fclose(f) == 0 && ok;
+}
+
+bool ReadBankCache(const std::string &filename, DetectorFile &out, unsigned long long yml_size, long long yml_mtime)
+{
+  FILE *f = fopen(filename.c_str(), "rb");
+  if (!f) return false;
+  BinR r{f};
+  char magic[8];
+  unsigned long long sz = 0;
+  long long mt = 0;
+  r.raw(magic, 8);
+  r.raw(&sz, 8);
+  r.raw(&mt, 8);
+  bool ok = r.ok && memcmp(magic, kBankMagic, 8) == 0 && sz == yml_size && mt == yml_mtime;
+  out = DetectorFile();
+  if (ok) {
+    out.pyramid_levels = r.i32();
+    int nT = r.i32();
+    for (int i = 0; r.ok && i < nT && nT < 64; ++i) out.T.push_back(r.i32());
+    int nm = r.i32();
+    for (int i = 0; r.ok && i < nm && nm < 64; ++i) out.modalities.push_back(r.str());
+    int nc = r.i32();
+    for (int ci = 0; r.ok && ci < nc; ++ci) {
+      ObjectClass oc;
+      oc.class_id = r.str();
+      int np = r.i32();
+      for (int p = 0; r.ok && p < np; ++p) {
+        int npose = r.i32();
+        std::vector<float> pose;
+        if (r.ok && npose >= 0 && npose < 1024) { pose.resize((size_t)npose); if (npose) r.raw(pose.data(), (size_t)npose * 4); } else r.ok = false;
+        oc.poses.push_back(pose);
+        int nt = r.i32();
+        std::vector<Template> pyr;
+        for (int ti = 0; r.ok && ti < nt && nt < 1024; ++ti) {
+          int hdr[6] = {0};
+          r.raw(hdr, sizeof(hdr));
+          Template t;
+          t.width = hdr[0]; t.height = hdr[1]; t.offset_x = hdr[2]; t.offset_y = hdr[3]; t.pyramid_level = hdr[4];
+          if (r.ok && hdr[5] >= 0 && hdr[5] < (1 << 20)) { t.features.resize((size_t)hdr[5]); if (hdr[5]) r.raw(t.features.data(), (size_t)hdr[5] * sizeof(Feature)); } else r.ok = false;
+          pyr.push_back(t);
+        }
+        oc.template_pyramids.push_back(pyr);
+      }
+      out.classes.push_back(oc);
+    }
+    ok = r.ok;
+  }
+  fclose(f);
+  if (!ok) out = DetectorFile();
+  return ok;
+}
+
+// readLinemod through the cache: <file>.flbank next to the YAML, rebuilt whenever the YAML's size or mtime changes
+bool ReadLinemodCached(const std::string &filename, DetectorFile &out, std::string *err, bool *from_cache)
+{
+  struct stat st;
+  if (from_cache) *from_cache = false;
+  if (stat(filename.c_str(), &st) != 0) { if (err) *err = "cannot open " + filename; return false; }
+  const std::string cache = filename + ".flbank";
+  if (ReadBankCache(cache, out, (unsigned long long)st.st_size, (long long)st.st_mtime)) {
+    if (from_cache) *from_cache = true;
+    return true;
+  }
+  if (!ReadLinemod(filename, out, err)) return false;
+  (void)WriteBankCache(out, cache, (unsigned long long)st.st_size, (long long)st.st_mtime);   // best effort (read-only dirs)
   return true;
 }
 

@@ -121,6 +121,11 @@ struct DetectorFile {            // what linemod_templates.yml holds (linemod.cp
 bool ReadLinemod(const std::string &filename, DetectorFile &out, std::string *err);
 // writeLinemod (linemod_if.cpp:49-63)
 bool WriteLinemod(const DetectorFile &det, const std::string &filename);
+// packed binary cache of the same content (<yml>.flbank, keyed by the YAML's size and mtime); ReadLinemodCached =
+// readLinemod that uses / refreshes it
+bool WriteBankCache(const DetectorFile &det, const std::string &filename, unsigned long long yml_size, long long yml_mtime);
+bool ReadBankCache(const std::string &filename, DetectorFile &out, unsigned long long yml_size, long long yml_mtime);
+bool ReadLinemodCached(const std::string &filename, DetectorFile &out, std::string *err, bool *from_cache);
 // imread(path, -1) for the 16-bit single-channel depth PNGs (obj_reco_lmicp.cpp:157)
 bool ReadPng16(const std::string &filename, std::vector<unsigned short> &pixels, int &w, int &h, std::string *err);
 

@@ -48,7 +48,7 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
     if (!m_ctx) return (int)ERROR_UNKNOW;
     fealess::DetectorFile df;
     std::string err;
-    if (!fealess::ReadLinemod(str_feature_path + "/linemod_templates.yml", df, &err) || df.classes.empty())
+    if (!fealess::ReadLinemodCached(str_feature_path + "/linemod_templates.yml", df, &err, nullptr) || df.classes.empty())
       return (int)ERROR_OPEN_FILE_FAILED;                                   // numClasses() == 0 (:71-72)
     if (m_det) { fl_detector_destroy(m_det); m_det = nullptr; }
     const int M = (int)df.modalities.size(), L = df.pyramid_levels;
@@ -234,6 +234,22 @@ int cadreco_recognition(void *h, const unsigned char *bgr, const unsigned short 
     snprintf(tag, tag_cap, "%s", out[0].strObjTag.c_str());
   }
   return rc;
+}
+int cadreco_read_linemod_cached(const char *path, int *from_cache, int *n_templates, int *n_features)
+{
+  fealess::DetectorFile df;
+  std::string err;
+  bool fc = false;
+  if (!fealess::ReadLinemodCached(path, df, &err, &fc)) return -1;
+  *from_cache = fc ? 1 : 0;
+  *n_templates = 0;
+  *n_features = 0;
+  for (auto &c : df.classes)
+    for (auto &p : c.template_pyramids) {
+      ++*n_templates;
+      for (auto &t : p) *n_features += (int)t.features.size();
+    }
+  return 0;
 }
 int cadreco_read_linemod(const char *path, int *levels, int *n_classes, int *n_templates, int *n_features)
 {

@@ -150,6 +150,22 @@ def test_linemod_yaml_reader(tmp_path):
     assert lib.cadreco_read_linemod(p.encode(), C.byref(lv), C.byref(nc), C.byref(nt), C.byref(nf)) == 0
     assert (lv.value, nc.value, nt.value, nf.value) == (2, 1, 7, 7 * 2 * (63 + 31))
     assert b"HIP" in lib.cadreco_version()
+    # packed binary cache next to the YAML: written on the first read, used on the second,
+    # ignored again as soon as the YAML changes
+    fc = C.c_int(-1)
+    assert lib.cadreco_read_linemod_cached(p.encode(), C.byref(fc), C.byref(nt), C.byref(nf)) == 0
+    assert fc.value == 0 and os.path.exists(p + ".flbank") and (nt.value, nf.value) == (7, 7 * 2 * (63 + 31))
+    assert lib.cadreco_read_linemod_cached(p.encode(), C.byref(fc), C.byref(nt), C.byref(nf)) == 0
+    assert fc.value == 1 and (nt.value, nf.value) == (7, 7 * 2 * (63 + 31))
+    bank2 = synth.make_bank("c919-jig", 9, 2, 2, 640, 480, seed=4)
+    write_linemod_yaml(p, bank2, [5, 8])
+    os.utime(p, (1, 1))                                      # a different mtime even within the same second
+    assert lib.cadreco_read_linemod_cached(p.encode(), C.byref(fc), C.byref(nt), C.byref(nf)) == 0
+    assert fc.value == 0 and nt.value == 9
+    with open(p + ".flbank", "r+b") as f:                    # a truncated / corrupt cache is ignored, not trusted
+        f.truncate(40)
+    assert lib.cadreco_read_linemod_cached(p.encode(), C.byref(fc), C.byref(nt), C.byref(nf)) == 0
+    assert fc.value == 0 and nt.value == 9
 
 
 def test_cadreco_factory_rejects_unsupported_types():
