@@ -268,6 +268,26 @@ class Detector:
         self.ctx.check(self.lib.fl_recognize_batch(self.h, n, bp, dp, L.FL_MEM_HOST, C.byref(k), C.byref(p), res))
         return [recognition_result_to_dict(r) for r in res]
 
+    def recognize_topk(self, bgr, depth, K, k, threshold=75.0, icp_it_thr=10, dist_mean_thr=0.5, dist_diff_thr=0.01,
+                       mode=L.FL_ICP_PARITY):
+        """Refinement of the first k matches of one frame; list of result dicts."""
+        b = np.ascontiguousarray(bgr, np.uint8)
+        d = np.ascontiguousarray(depth, np.uint16)
+        kk = L.Intrinsics(self.w0, self.h0, *K)
+        p = self._params(threshold, icp_it_thr, dist_mean_thr, dist_diff_thr, mode)
+        res = (L.RecognitionResult * k)()
+        n = C.c_int(0)
+        self.ctx.check(self.lib.fl_recognize_topk(self.h, _ptr(b), _ptr(d), L.FL_MEM_HOST, C.byref(kk), C.byref(p), k, res, C.byref(n)))
+        self._last_topk = res
+        return [recognition_result_to_dict(res[i]) for i in range(n.value)]
+
+    def nms(self, n, th_obj_dist):
+        """nonMaximumSuppression (ICP/NMS.cpp:6-40) over the first n hypotheses of the last recognize_topk call."""
+        win = (C.c_int * max(1, n))()
+        nw = C.c_int(0)
+        self.ctx.check(self.lib.fl_nms(self._last_topk, n, th_obj_dist, win, C.byref(nw)))
+        return [int(win[i]) for i in range(nw.value)]
+
     def recognize_submit_device(self, bgr_ptrs, depth_ptrs, K, params):
         n = len(bgr_ptrs)
         bp = (C.c_void_p * n)(*bgr_ptrs)

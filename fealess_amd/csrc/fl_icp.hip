@@ -98,7 +98,9 @@ struct IcpArgs {
   int mode;
   IcpJob job;            // kinds 1, 2
   // kind 0: recognition batch
-  const uint8_t *frame_ws;   // detector frame workspaces (same stride)
+  const uint8_t *frame_ws;   // detector frame workspaces
+  size_t frame_stride;       // their stride (= ws_stride in the per-frame pipeline)
+  int ranks;                 // hypotheses per frame: workgroup b refines match (b % ranks) of frame (b / ranks)
   size_t off_count, off_match;
   const uint16_t *scene_base;   // frame i's depth = scene_base + i*scene_stride (bytes)
   size_t scene_stride;
@@ -1028,13 +1030,13 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
-  const int frame = blockIdx.x;
+  const int job = blockIdx.x, frame = a.job.kind == 0 ? job / a.ranks : job, rank = a.job.kind == 0 ? job % a.ranks : 0;
   const IcpWsLayout L = icp_layout(a.n_max);
-  uint8_t *wsb = a.ws + (size_t)frame * a.ws_stride;
+  uint8_t *wsb = a.ws + (size_t)job * a.ws_stride;
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
 
 
-  fl_recognition_result *res = &a.results[frame];
+  fl_recognition_result *res = &a.results[job];
   const uint16_t *scene, *model;
   float r_match[9], t_match[3];
   bool model_01mm;
@@ -1053,7 +1055,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
   } else {
     // CObjRecoLmICP::Recognition after Detector::match (obj_reco_lmicp.cpp:106-152)
-    const uint8_t *fws = a.frame_ws + (size_t)frame * a.ws_stride;
+    const uint8_t *fws = a.frame_ws + (size_t)frame * a.frame_stride;
     const int *counters = (const int *)(fws + a.off_count);
     const fl_match *matches = (const fl_match *)(fws + a.off_match);
     if (threadIdx.x == 0) {
@@ -1063,8 +1065,8 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       res->found = 0;
       res->status = FL_OK;
       if (counters[2]) S.status = res->status = FL_ERR_OVERFLOW;
-      else if (counters[1] > 0) {
-        const fl_match best = matches[0];                // matches[0] :111
+      else if (counters[1] > rank) {
+        const fl_match best = matches[rank];             // matches[0] :111 (rank > 0: multi-hypothesis extension)
         res->best = best;
         const int g = a.class_first[best.class_idx] + best.template_id;
         const FlPyrInfo pi = a.pyr[g];
@@ -1316,6 +1318,43 @@ extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const 
 }
 
 // batch: one workgroup per frame of the detector workspace
+// Multi-hypothesis refinement of ONE frame: the first `k` matches of frame 0 are refined by k
+// workgroups of the same kernel, each with an ICP workspace of its own in `ws` (k * fl_icp_ws_bytes(n_pts_max)).
+int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, const fl_recognition_params *p, const uint16_t *depth,
+                             uint8_t *ws, fl_recognition_result *d_results)
+{
+  fl_context *ctx = det->ctx;
+  IcpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ws = ws;
+  a.ws_stride = fl_icp_ws_bytes(det->n_pts_max);
+  a.n_max = det->n_pts_max;
+  a.w = det->w0;
+  a.h = det->h0;
+  a.fx = (float)K->fx;
+  a.fy = (float)K->fy;
+  a.cx = (float)K->cx;
+  a.cy = (float)K->cy;
+  a.it_thr = p->icp_it_thr;
+  a.dmt = p->dist_mean_thr;
+  a.ddt = p->dist_diff_thr;
+  a.mode = p->icp_mode;
+  a.job.kind = 0;
+  a.frame_ws = det->d_ws;
+  a.frame_stride = det->ws_stride;
+  a.ranks = k;
+  a.scene_base = depth;
+  a.scene_stride = 0;
+  a.off_count = det->off_count;
+  a.off_match = det->off_match;
+  a.pyr = det->d_pyr;
+  a.class_first = det->d_class_first;
+  a.poses = det->d_poses;
+  a.depth_ptrs = det->d_depth_ptrs;
+  a.results = d_results;
+  return icp_launch(ctx, k, a);
+}
+
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *p,
                               const uint16_t *depth, size_t depth_stride)
 {
@@ -1337,6 +1376,8 @@ int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsic
   a.mode = p->icp_mode;
   a.job.kind = 0;
   a.frame_ws = det->d_ws;
+  a.frame_stride = det->ws_stride;
+  a.ranks = 1;
   a.scene_base = depth;
   a.scene_stride = depth_stride;
   a.off_count = det->off_count;

@@ -160,6 +160,9 @@ int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_
                        const uint16_t *depth, size_t depth_stride);
 // icp
 size_t fl_icp_ws_bytes(int n_pts_max);
+int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, const fl_recognition_params *p, const uint16_t *depth,
+                             uint8_t *ws, fl_recognition_result *d_results);
+size_t fl_icp_ws_bytes(int n_pts_max);
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K,
                               const fl_recognition_params *p, const uint16_t *depth,
                               size_t depth_stride);

@@ -5,6 +5,8 @@
 // whole batch (grid.z / grid.y / one workgroup per frame), so the launch count per batch is
 // constant (about a dozen) whatever the number of frames.
 #include "fl_internal.h"
+#include <cmath>
+#include <vector>
 #include <string.h>
 
 static bool uniform_stride(const void *const *ptrs, int n, size_t min_bytes, size_t *stride)
@@ -108,6 +110,68 @@ extern "C" int fl_recognize_batch(fl_detector *det, int n_frames, const uint8_t 
   int rc = fl_recognize_submit(det, n_frames, bgr, depth, mem, K, params);
   if (rc) return rc;
   return fl_recognize_collect(det, n_frames, results);
+}
+
+// Multi-hypothesis recognition of one frame + nonMaximumSuppression (ICP/NMS.cpp, obj_data.h)
+extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, const fl_intrinsics *K,
+                                 const fl_recognition_params *params, int k, fl_recognition_result *results, int *n_results)
+{
+  if (!det || !bgr || !depth || !K || !params || !results || !n_results || k < 1 || k > 1024) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
+  if (det->M != 2) return fl_set_error(ctx, FL_ERR_INVALID, "needs the colour + depth modalities");
+  if (K->width != det->w0 || K->height != det->h0)
+    return fl_set_error(ctx, FL_ERR_INVALID, "intrinsics are %dx%d, detector finalized for %dx%d", K->width, K->height, det->w0, det->h0);
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_bgr, bgr, (size_t)det->w0 * det->h0 * 3, kind, ctx->stream));
+  FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_depth, depth, (size_t)det->w0 * det->h0 * 2, kind, ctx->stream));
+  det->have_times = false;
+  const uint16_t *d_depth = (const uint16_t *)(det->d_ws + det->off_depth);
+  int rc = fl_launch_frontend(det, 1, det->d_ws + det->off_bgr, det->ws_stride, d_depth, det->ws_stride);
+  if (rc) return rc;
+  rc = fl_launch_match_core(det, 1, params->matching_threshold);
+  if (rc) return rc;
+  const size_t icp_bytes = fl_align(fl_icp_ws_bytes(det->n_pts_max), 256) * (size_t)k, res_bytes = sizeof(fl_recognition_result) * (size_t)k;
+  void *sv = nullptr;
+  if ((rc = fl_scratch(ctx, icp_bytes + fl_align(res_bytes, 256), &sv))) return rc;
+  fl_recognition_result *d_res = (fl_recognition_result *)((uint8_t *)sv + icp_bytes);
+  FL_HIP(ctx, hipMemsetAsync(d_res, 0, res_bytes, ctx->stream));
+  if ((rc = fl_launch_detection_topk(det, k, K, params, d_depth, (uint8_t *)sv, d_res))) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(results, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  det->last_batch = 1;
+  det->last_from_images = true;
+  if (results[0].status == FL_ERR_OVERFLOW) return fl_set_error(ctx, FL_ERR_OVERFLOW, "more than %d candidates in the frame", det->cap);
+  const int n = results[0].n_matches < k ? results[0].n_matches : k;
+  *n_results = n < 0 ? 0 : n;
+  return FL_OK;
+}
+
+// nonMaximumSuppression (ICP/NMS.cpp:6-40) over refined hypotheses, in list order.  winners[g] = index of the
+// hypothesis that represents group g; returns the number of groups in *n_winners.  Host-only arithmetic.
+extern "C" int fl_nms(const fl_recognition_result *objs, int n, float th_obj_dist, int *winners, int *n_winners)
+{
+  if ((n > 0 && !objs) || !winners || !n_winners || n < 0) return FL_ERR_INVALID;
+  std::vector<char> done((size_t)(n > 0 ? n : 1), 0);
+  int n_out = 0;
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    int o = i;
+    const int size_th = static_cast<int>((float)objs[i].det.n_points * 0.85);
+    for (int j = i + 1; j < n; ++j) {
+      if (done[j]) continue;
+      double s = 0;
+      for (int c = 0; c < 3; ++c) { const double d = (double)objs[o].det.T_final[c] - (double)objs[j].det.T_final[c]; s += d * d; }
+      if (std::sqrt(s) < th_obj_dist) {
+        done[j] = 1;
+        if (objs[j].det.n_points > size_th && objs[j].det.icp.dist_mean < objs[o].det.icp.dist_mean) o = j;
+      }
+    }
+    winners[n_out++] = o;
+  }
+  *n_winners = n_out;
+  return FL_OK;
 }
 
 extern "C" int fl_last_stage_times(fl_detector *det, fl_stage_times *out)

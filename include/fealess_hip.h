@@ -223,6 +223,15 @@ int  fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t *const *b
 int  fl_recognize_collect(fl_detector *det, int n_frames, fl_recognition_result *results);
 
 /* ---- multi-GPU support: top-k records for the all-gather ------------------------------------ */
+/* Multi-hypothesis recognition (the pipeline ICP/NMS.cpp + obj_data.h sketch): the refinement of
+ * Recognition() (obj_reco_lmicp.cpp:111-197) for the first k matches of ONE frame, k ICP workgroups in one launch.
+ * results[r] (host, r < *n_results = min(k, matches)) has the same content fl_recognize_batch gives for matches[0];
+ * a hypothesis whose crop leaves the image has found = 0 and status = FL_ERR_ASSERT. */
+int  fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, const fl_intrinsics *K,
+                       const fl_recognition_params *params, int k, fl_recognition_result *results, int *n_results);
+/* nonMaximumSuppression (ICP/NMS.cpp:6-40) over refined hypotheses in list order: winners[g] = index of the
+ * hypothesis representing group g (translation closer than th_obj_dist to the group's current best). Host only. */
+int  fl_nms(const fl_recognition_result *objs, int n, float th_obj_dist, int *winners, int *n_winners);
 /* After fl_match_frame / fl_recognize_submit: copy frame `frame`'s first k sorted matches into a
  * device buffer (k * sizeof(fl_match) bytes, padded with template_id = -1) for an RCCL
  * all-gather by the caller; template ids are offset by template_id_base (the shard's first

@@ -172,6 +172,13 @@ int  orc_recognition(const uint8_t *bgr, const uint16_t *depth, int w, int h,
                      float threshold, int icp_it_thr, float dist_mean_thr, float dist_diff_thr,
                      int accum64, int use_kdtree, orc_recognition_result *res);
 
+/* multi-hypothesis refinement + nonMaximumSuppression (ICP/NMS.cpp:6-40, obj_data.h) */
+int orc_recognition_topk(const uint8_t *bgr, const uint16_t *depth, int w, int h, double fx, double fy, double cx, double cy,
+                         int levels, const int *T_at_level, const orc_bank *bank, const float *poses13,
+                         const uint16_t *const *model_depths_01mm, float threshold, int icp_it_thr, float dist_mean_thr,
+                         float dist_diff_thr, int accum64, int use_kdtree, int k, orc_recognition_result *results);
+int orc_nms(const orc_recognition_result *objs, int n, float th_obj_dist, int *winners);
+
 #ifdef __cplusplus
 }
 #endif

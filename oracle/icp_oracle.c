@@ -499,20 +499,12 @@ int orc_detection(const uint16_t *model_depth, const uint16_t *scene_depth, int 
 }
 
 /* CObjRecoLmICP::Recognition (CadReco/obj_reco_lmicp.cpp:86-204), input already 640 wide */
-int orc_recognition(const uint8_t *bgr, const uint16_t *depth, int w, int h,
-                    double fx, double fy, double cx, double cy,
-                    int levels, const int *T_at_level, const orc_bank *bank,
-                    const float *poses13, const uint16_t *const *model_depths_01mm,
-                    float threshold, int icp_it_thr, float dist_mean_thr, float dist_diff_thr,
-                    int accum64, int use_kdtree, orc_recognition_result *res)
+/* the part of Recognition() after the match has been chosen (obj_reco_lmicp.cpp:111-197) */
+static int recognition_refine(const orc_match best, const uint16_t *depth, int w, int h, double fx, double fy, double cx, double cy,
+                              const orc_bank *bank, const float *poses13, const uint16_t *const *model_depths_01mm,
+                              int icp_it_thr, float dist_mean_thr, float dist_diff_thr, int accum64, int use_kdtree,
+                              orc_recognition_result *res)
 {
-  memset(res, 0, sizeof(*res));
-  orc_match best;
-  int n_total = 0;
-  int n = orc_match_images(bgr, depth, w, h, levels, T_at_level, bank, 1, threshold, &best, 1, &n_total, NULL);
-  if (n < 0) return -1;                                  /* ERROR_INVALID_PARAM :102-105 */
-  res->n_matches = n_total;
-  if (n == 0) return 0;                                  /* :106-109 */
   res->found = 1;
   res->best = best;
   const orc_template *t0 = bank->templates + (size_t)best.template_id * bank->levels * bank->modalities;
@@ -543,4 +535,71 @@ int orc_recognition(const uint8_t *bgr, const uint16_t *depth, int w, int h,
   res->pose[12] = res->pose[13] = res->pose[14] = 0;
   res->pose[15] = 1;
   return 0;
+}
+
+int orc_recognition(const uint8_t *bgr, const uint16_t *depth, int w, int h,
+                    double fx, double fy, double cx, double cy,
+                    int levels, const int *T_at_level, const orc_bank *bank,
+                    const float *poses13, const uint16_t *const *model_depths_01mm,
+                    float threshold, int icp_it_thr, float dist_mean_thr, float dist_diff_thr,
+                    int accum64, int use_kdtree, orc_recognition_result *res)
+{
+  memset(res, 0, sizeof(*res));
+  orc_match best;
+  int n_total = 0;
+  int n = orc_match_images(bgr, depth, w, h, levels, T_at_level, bank, 1, threshold, &best, 1, &n_total, NULL);
+  if (n < 0) return -1;                                  /* ERROR_INVALID_PARAM :102-105 */
+  res->n_matches = n_total;
+  if (n == 0) return 0;                                  /* :106-109 */
+  return recognition_refine(best, depth, w, h, fx, fy, cx, cy, bank, poses13, model_depths_01mm, icp_it_thr, dist_mean_thr,
+                            dist_diff_thr, accum64, use_kdtree, res);
+}
+
+/* SURVEY 8f rank 3 -- the multi-hypothesis pipeline the reference's dead code sketches: the same refinement for the
+ * first k matches instead of matches[0] only (results[r] for r < min(k, n_matches); returns that count or -1) ... */
+int orc_recognition_topk(const uint8_t *bgr, const uint16_t *depth, int w, int h, double fx, double fy, double cx, double cy,
+                         int levels, const int *T_at_level, const orc_bank *bank, const float *poses13,
+                         const uint16_t *const *model_depths_01mm, float threshold, int icp_it_thr, float dist_mean_thr,
+                         float dist_diff_thr, int accum64, int use_kdtree, int k, orc_recognition_result *results)
+{
+  orc_match *m = (orc_match *)malloc(sizeof(orc_match) * (size_t)(k > 0 ? k : 1));
+  int n_total = 0;
+  int n = orc_match_images(bgr, depth, w, h, levels, T_at_level, bank, 1, threshold, m, k, &n_total, NULL);
+  if (n < 0) { free(m); return -1; }
+  for (int r = 0; r < n; ++r) {
+    memset(&results[r], 0, sizeof(results[r]));
+    results[r].n_matches = n_total;
+    int rc = recognition_refine(m[r], depth, w, h, fx, fy, cx, cy, bank, poses13, model_depths_01mm, icp_it_thr, dist_mean_thr,
+                                dist_diff_thr, accum64, use_kdtree, &results[r]);
+    if (rc) results[r].found = 0;                        /* e.g. Q10: the crop leaves the image -- this hypothesis is skipped */
+  }
+  free(m);
+  return n;
+}
+
+/* ... and nonMaximumSuppression (ICP/NMS.cpp:6-40) over the refined hypotheses, in list order: a hypothesis not yet
+ * absorbed opens a group; every later one within th_obj_dist of the group's CURRENT best (cv::norm of the t
+ * difference, double accumulate) is absorbed, and replaces the best if it has more than 0.85 x the opener's points
+ * and a smaller ICP distance.  Writes the index of each group's winner; returns the number of groups. */
+int orc_nms(const orc_recognition_result *objs, int n, float th_obj_dist, int *winners)
+{
+  char *done = (char *)calloc((size_t)(n > 0 ? n : 1), 1);
+  int n_out = 0;
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    int o = i;
+    const int size_th = (int)((float)objs[i].det.n_points * 0.85);
+    for (int j = i + 1; j < n; ++j) {
+      if (done[j]) continue;
+      double s = 0;
+      for (int c = 0; c < 3; ++c) { double d = (double)objs[o].det.T_final[c] - (double)objs[j].det.T_final[c]; s += d * d; }
+      if (sqrt(s) < th_obj_dist) {
+        done[j] = 1;
+        if (objs[j].det.n_points > size_th && objs[j].det.icp.dist_mean < objs[o].det.icp.dist_mean) o = j;
+      }
+    }
+    winners[n_out++] = o;
+  }
+  free(done);
+  return n_out;
 }

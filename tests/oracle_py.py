@@ -359,3 +359,39 @@ def recognition(bgr, depth, K, T_pyramid, bank, threshold=75.0, icp_it_thr=10, d
                 det=dict(R_final=np.array(res.det.R_final, np.float32).reshape(3, 3),
                          T_final=np.array(res.det.T_final, np.float32), icp=_icp_dict(res.det.icp),
                          n_points=int(res.det.n_points)))
+
+
+def _reco_dict(res, rc=0):
+    return dict(rc=rc, found=int(res.found), n_matches=int(res.n_matches),
+                best=dict(x=res.best.x, y=res.best.y, similarity=np.float32(res.best.similarity),
+                          class_idx=res.best.class_idx, template_id=res.best.template_id),
+                pose=np.array(res.pose, np.float32).reshape(4, 4),
+                det=dict(R_final=np.array(res.det.R_final, np.float32).reshape(3, 3),
+                         T_final=np.array(res.det.T_final, np.float32), icp=_icp_dict(res.det.icp),
+                         n_points=int(res.det.n_points)))
+
+
+def recognition_topk(bgr, depth, K, T_pyramid, bank, k, threshold=75.0, icp_it_thr=10, dist_mean_thr=0.5, dist_diff_thr=0.01,
+                     nms_dist=None):
+    """First k matches refined like Recognition() does for matches[0]; with nms_dist also the NMS winners."""
+    b = np.ascontiguousarray(bgr, np.uint8)
+    d = np.ascontiguousarray(depth, np.uint16)
+    h, w = d.shape
+    levels = len(T_pyramid)
+    T = (C.c_int * levels)(*T_pyramid)
+    arr, keep = _banks([bank])
+    t, f, p = keep[0]
+    mds = [np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
+    mptr = (C.c_void_p * len(mds))(*[m.ctypes.data for m in mds])
+    res = (OrcRecognitionResult * k)()
+    n = lib().orc_recognition_topk(_p(b), _p(d), w, h, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
+                                   levels, T, C.byref(arr[0]), _p(p), mptr, C.c_float(threshold), icp_it_thr,
+                                   C.c_float(dist_mean_thr), C.c_float(dist_diff_thr), 0, 1, k, res)
+    if n < 0:
+        raise AssertionError("reference CV_Assert")
+    out = [_reco_dict(res[i]) for i in range(n)]
+    if nms_dist is None:
+        return out
+    win = (C.c_int * max(1, n))()
+    nw = lib().orc_nms(res, n, C.c_float(nms_dist), win)
+    return out, [int(win[i]) for i in range(nw)]

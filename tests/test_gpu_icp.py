@@ -195,3 +195,29 @@ def test_icp_degenerate_clouds(ctx, oracle):
         assert got["iters"] == exp["iters"] and got["n_corr_last"] == exp["n_corr_last"]
         assert np.array_equal(np.isnan(got["R"]), np.isnan(exp["R"]))
         assert np.abs(np.nan_to_num(got["R"]) - np.nan_to_num(exp["R"])).max() <= POSE_TOL
+
+
+def test_multi_hypothesis_topk_and_nms(ctx, oracle):
+    """the first k matches refined in one launch (k ICP workgroups) + nonMaximumSuppression
+    (ICP/NMS.cpp:6-40): every hypothesis equals the oracle's refinement of the same match, bit for bit."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=21, n_views=6)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480)
+    k = 6
+    got = det.recognize_topk(sc["bgr"], sc["depth"], sc["K"], k, 60.0, 8, 0.3, 0.01)
+    exp, win_exp = oracle.recognition_topk(sc["bgr"], sc["depth"], sc["K"], [5, 8], sc["bank"], k, 60.0, 8, 0.3, 0.01, nms_dist=20.0)
+    assert len(got) == len(exp) >= 2
+    for g, e in zip(got, exp):
+        assert g["found"] == e["found"] and g["best"]["template_id"] == e["best"]["template_id"]
+        assert (g["best"]["x"], g["best"]["y"]) == (e["best"]["x"], e["best"]["y"])
+        if e["found"]:
+            assert np.array_equal(_bits(g["pose"]), _bits(e["pose"])) and g["det"]["n_points"] == e["det"]["n_points"]
+            assert _bits(g["det"]["icp"]["dist_mean"]) == _bits(e["det"]["icp"]["dist_mean"])
+    # hypothesis 0 is what Recognition() returns
+    r0 = det.recognize_batch([sc["bgr"]], [sc["depth"]], sc["K"], 60.0, 8, 0.3, 0.01)[0]
+    assert np.array_equal(_bits(r0["pose"]), _bits(got[0]["pose"]))
+    assert det.nms(len(got), 20.0) == win_exp and len(win_exp) >= 1
+    assert det.nms(len(got), 0.0) == list(range(len(got)))          # nothing is closer than 0: every hypothesis survives
+    assert det.nms(len(got), 1e9) in ([0], [win_exp[0]]) and len(det.nms(len(got), 1e9)) == 1
+    det.close()

@@ -385,3 +385,25 @@ def test_extract_template_semantics(oracle):
     assert sorted((int(a), int(b)) for a, b in zip(got["x"], got["y"])) == sorted(pts)
     assert oracle.extract_template_color(qq, mg, None, 55.0, 5) is None                # too few candidates
     assert oracle.add_template(np.zeros((480, 640, 3), np.uint8), np.full((480, 640), 1000, np.uint16), None, 2) is None
+
+
+def test_nms_semantics(oracle):
+    """nonMaximumSuppression (ICP/NMS.cpp:6-40) on hand-made hypotheses: groups by distance to the group's CURRENT
+    best, replacement needs > 0.85 x the opener's points and a smaller ICP distance."""
+    import ctypes as C
+    objs = (oracle.OrcRecognitionResult * 5)()
+
+    def setup(i, t, npts, dist):
+        objs[i].det.T_final[0], objs[i].det.T_final[1], objs[i].det.T_final[2] = t
+        objs[i].det.n_points = npts
+        objs[i].det.icp.dist_mean = dist
+    setup(0, (0, 0, 0), 1000, 2.0)
+    setup(1, (5, 0, 0), 900, 1.0)        # near 0, enough points, better -> becomes the best of group 0
+    setup(2, (12, 0, 0), 2000, 0.5)      # 12 from object 0 but 7 from the new best (object 1) -> absorbed; better -> wins
+    setup(3, (100, 0, 0), 10, 0.1)       # far away -> its own group
+    setup(4, (103, 0, 0), 8, 0.01)       # near 3 but 8 <= int(10 * 0.85) = 8 points -> absorbed without replacing
+    win = (C.c_int * 5)()
+    n = oracle.lib().orc_nms(objs, 5, C.c_float(10.0), win)
+    assert [win[i] for i in range(n)] == [2, 3]
+    n = oracle.lib().orc_nms(objs, 5, C.c_float(6.0), win)      # 2 is now 7 > 6 from the best of group 0
+    assert [win[i] for i in range(n)] == [1, 2, 3]
