@@ -51,25 +51,23 @@ def parse():
 
 def build_workload(ctx, args, rank):
     """Synthetic frames + template bank.  Templates = rendered views of the
-    object near each scene pose (they win the detection and feed ICP with real clouds) padded with
-    random templates (the scan's work is data-independent).  Quantisation for the rendered views
-    uses the HIP path itself (the oracle is never touched outside the cpu_baseline leg)."""
+    object near each scene pose, trained with the product's own addTemplate (fl_extract_template_pyramid; they
+    win the detection and feed ICP with real clouds), padded with random templates (the scan's work is
+    data-independent).  The oracle is never touched outside the cpu_baseline leg."""
     from fealess_amd import synth
     from fealess_amd.bank import TemplateBank
     levels = args.levels
     w, h = 640, 480
 
-    def quantize_fn(bgr, depth, lv):
-        out = []
-        src = bgr
-        qn = ctx.quantized_normals(depth)
-        for l in range(lv):
-            if l > 0:
-                src = ctx.pyrdown_bgr(src)
-                qn = np.ascontiguousarray(qn[::2, ::2][:qn.shape[0] // 2, :qn.shape[1] // 2])
-            out.append(ctx.quantized_orientations(src))
-            out.append(qn)
-        return out
+    def trained_template(Rv, tv, seed):
+        """One training view through the product's own Detector::addTemplate (fl_extract_template_pyramid): the
+        rendered object with its mask -> template pyramid, 13-float pose, depth render in 0.1 mm."""
+        d_bg, bgr_v, mask = synth.render(w, h, Rv, tv, seed=seed, noise=False, background=True)
+        ex = ctx.extract_template_pyramid(bgr_v, d_bg, (mask * 255).astype(np.uint8), levels)
+        if ex is None:
+            return None
+        d_obj, _, _ = synth.render(w, h, Rv, tv, seed=seed, noise=False, background=False)
+        return ex[0], synth.pose13(Rv, tv), (d_obj.astype(np.uint32) * 10).clip(0, 65535).astype(np.uint16)
 
     rng = np.random.default_rng(1234)        # same bank on every rank
     bank = TemplateBank("obj", levels, 2)
@@ -83,7 +81,7 @@ def build_workload(ctx, args, rank):
         for v in range(2):
             dR = synth.rot_z(np.deg2rad(rng.uniform(-2, 2))) @ synth.rot_x(np.deg2rad(rng.uniform(-2, 2)))
             tt = t + np.array([rng.uniform(-20, 20), rng.uniform(-15, 15), rng.uniform(-8, 8)])
-            out = synth.rendered_template(quantize_fn, dR @ R, tt, levels, w, h, seed=1000 + 10 * s + v)
+            out = trained_template(dR @ R, tt, seed=1000 + 10 * s + v)
             if out is not None and bank.n_pyramids < args.templates:
                 bank.add_pyramid(*out)
     zero = np.zeros((h, w), np.uint16)
