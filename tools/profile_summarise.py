@@ -17,13 +17,19 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
 out = os.path.join(ROOT, "profiles")
 src = os.path.join(ROOT, "gpurun_out")
 
-stats = glob.glob(os.path.join(src, "prof_final", "**", "*kernel_stats.csv"), recursive=True)
+# gpurun merges every call's output into gpurun_out/, so older runs may still be there: take the newest file only
+stats = sorted(glob.glob(os.path.join(src, "prof_final", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 assert stats, "no kernel_stats.csv under gpurun_out/prof_final"
-shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+shutil.copy(stats[-1], os.path.join(out, f"{tag}_kernel_stats.csv"))
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
+newest = {}
 for f in glob.glob(os.path.join(src, "pmc_final_*", "**", "*counter_collection.csv"), recursive=True):
+    grp = os.path.relpath(f, src).split(os.sep)[0]
+    if grp not in newest or os.path.getmtime(f) > os.path.getmtime(newest[grp]):
+        newest[grp] = f
+for f in newest.values():
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
