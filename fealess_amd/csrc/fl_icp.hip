@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(FL_ICP_WPE, FL_ICP_WPE))) void k_icp_pipeline(IcpArgs a)
+__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == FL_ICP_PARITY ? FL_ICP_WPE : 1, MODE == FL_ICP_PARITY ? FL_ICP_WPE : 4))) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
