@@ -395,3 +395,17 @@ def recognition_topk(bgr, depth, K, T_pyramid, bank, k, threshold=75.0, icp_it_t
     win = (C.c_int * max(1, n))()
     nw = lib().orc_nms(res, n, C.c_float(nms_dist), win)
     return out, [int(win[i]) for i in range(nw)]
+
+
+def gaussian7_bgr(bgr):
+    b = np.ascontiguousarray(bgr, np.uint8)
+    out = np.zeros_like(b)
+    lib().orc_gaussian7_bgr(_p(b), b.shape[1], b.shape[0], _p(out))
+    return out
+
+
+def median5(img):
+    m = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(m)
+    lib().orc_median5(_p(m), m.shape[1], m.shape[0], _p(out))
+    return out

@@ -407,3 +407,42 @@ def test_nms_semantics(oracle):
     assert [win[i] for i in range(n)] == [2, 3]
     n = oracle.lib().orc_nms(objs, 5, C.c_float(6.0), win)      # 2 is now 7 > 6 from the best of group 0
     assert [win[i] for i in range(n)] == [1, 2, 3]
+
+
+def test_filters_and_nn_pinned_against_scipy(oracle):
+    """The oracle's restatements of OpenCV's separable filters and of the exact nearest-neighbour search against
+    independent implementations (scipy): what remains unpinned is only OpenCV's choice of kernel and rounding, as
+    published -- not our arithmetic."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    sp = pytest.importorskip("scipy.spatial")
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    # GaussianBlur 7x7, sigma from ksize, 8-bit path: separable {8,28,56,72,56,28,8}/256 twice, ONE rounding (acc + 2^15) >> 16
+    k = np.array([8, 28, 56, 72, 56, 28, 8], np.int64)
+    acc = ndi.correlate1d(ndi.correlate1d(img.astype(np.int64), k, axis=1, mode="nearest"), k, axis=0, mode="nearest")
+    assert np.array_equal(oracle.gaussian7_bgr(img), ((acc + (1 << 15)) >> 16).astype(np.uint8))
+    # medianBlur 5, BORDER_REPLICATE
+    q = (1 << rng.integers(0, 8, (41, 29))).astype(np.uint8) * (rng.random((41, 29)) < 0.7)
+    assert np.array_equal(oracle.median5(q.astype(np.uint8)), ndi.median_filter(q.astype(np.uint8), size=5, mode="nearest"))
+    # pyrDown: [1 4 6 4 1]^2 / 256 with REFLECT_101 (scipy: "mirror"), (acc + 128) >> 8, even samples
+    k5 = np.array([1, 4, 6, 4, 1], np.int64)
+    big = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    acc = ndi.correlate1d(ndi.correlate1d(big.astype(np.int64), k5, axis=1, mode="mirror"), k5, axis=0, mode="mirror")
+    assert np.array_equal(oracle.pyrdown_bgr(big), ((acc[::2, ::2] + 128) >> 8).astype(np.uint8))
+    # exact 1-NN of the ICP (kd-tree oracle path) against scipy's cKDTree: the number of pairs kept in iteration 2
+    # (d^2 <= 3 * dist_mean, ICP.cpp:268) must equal the count obtained from an independent exact NN search on the
+    # model transformed by iteration 1's (R, T)
+    ref = rng.normal(0, 30, (700, 3)).astype(np.float32)
+    ref[:, 2] += 400
+    model = (ref + rng.normal(0, 0.7, ref.shape)).astype(np.float32)
+    r = oracle.icp(ref, model, 2, 0.0, -3.0e38, accum64=False, use_kdtree=True, trace=True)
+    assert r["iters"] == 2
+    n1, dm1 = r["trace"][0][0], np.float32(r["trace"][0][1])
+    R1, T1 = r["trace"][0][11:20].reshape(3, 3).astype(np.float32), r["trace"][0][20:23].astype(np.float32)
+    assert int(n1) == len(model)                                  # iteration 1 pairs by index
+    moved = np.empty_like(model)
+    for c in range(3):                                            # transformPoints: float32, (r0 x + r1 y) + r2 z, then + T
+        moved[:, c] = ((R1[c, 0] * model[:, 0] + R1[c, 1] * model[:, 1]) + R1[c, 2] * model[:, 2]) + T1[c]
+    d, j = sp.cKDTree(ref.astype(np.float64)).query(moved.astype(np.float64))
+    kept = int((d * d <= 3.0 * float(dm1)).sum())
+    assert abs(int(r["trace"][1][0]) - kept) <= 1                 # <= 1: a pair exactly on the float32 / float64 boundary
