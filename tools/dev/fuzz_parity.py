@@ -13,9 +13,13 @@ ctx = api.Context(0)
 t0 = time.time()
 stats = dict(icp=0, frontend=0, recognition=0, linemod=0, extract=0, fail=0)
 def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
-seed = 1000
+seed = int(os.environ.get("FUZZ_SEED", "1000"))
+last_print = t0
 while time.time() - t0 < budget:
     seed += 1
+    if time.time() - last_print > 45:                        # gpurun kills a command that is silent for 7 minutes
+        last_print = time.time()
+        print("progress:", stats, flush=True)
     rng = np.random.default_rng(seed)
     kind = seed % 5 if len(sys.argv) < 3 else int(sys.argv[2])
     try:
