@@ -446,9 +446,22 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
           if (in && lm_x + 15 < W && lm_y + 15 < H) {                      // wave-uniform: the usual case
             // the 16x16 patch stays inside its linear memory: position (row, col4 + c) is simply the
             // pixel (fy + row*T, fx + (col4 + c)*T)
+            // The lane's four positions are T bytes apart: for the usual T one (or two) 16-byte loads replace four
+            // byte loads -- the stage is bound by vector-memory instructions, 8 features x 4 in flight per step.
             const uint8_t *p0 = sp + (size_t)(fy * a.w + fx) + lane_off;
+            if (T == 5) {
+              const uint4 v = ld16(p0);                                     // bytes 0, 5, 10, 15
+              b[u][0] = v.x & 0xFFu; b[u][1] = (v.y >> 8) & 0xFFu; b[u][2] = (v.z >> 16) & 0xFFu; b[u][3] = v.w >> 24;
+            } else if (T == 4) {
+              const uint4 v = ld16(p0);                                     // bytes 0, 4, 8, 12
+              b[u][0] = v.x & 0xFFu; b[u][1] = v.y & 0xFFu; b[u][2] = v.z & 0xFFu; b[u][3] = v.w & 0xFFu;
+            } else if (T == 8) {
+              const uint4 v0 = ld16(p0), v1 = ld16(p0 + 16);                // bytes 0, 8 | 16, 24
+              b[u][0] = v0.x & 0xFFu; b[u][1] = v0.z & 0xFFu; b[u][2] = v1.x & 0xFFu; b[u][3] = v1.z & 0xFFu;
+            } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) b[u][c] = p0[c * T];
+              for (int c = 0; c < 4; ++c) b[u][c] = p0[c * T];
+            }
           } else {
             // rare: the patch leaves its linear memory (or the feature is out of the image); kept out
             // of line so the unrolled step stays small (instruction-cache footprint)
