@@ -492,6 +492,16 @@ __device__ __forceinline__ T ld_u32(const T *__restrict__ base, int idx)
   return *(const T *)((const char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
 }
 
+// one 12-byte load (global_load_dwordx3) for a point instead of three dword loads: the phases are bound by the
+// number of vector-memory instructions as much as by anything else
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
+{
+  F3 v;
+  __builtin_memcpy(&v, (const char *)base + (size_t)((unsigned)i * 12u), 12);
+  return v;
+}
+
 // the grid parameters as wave-uniform scalars (SGPRs): read from LDS they would each cost a VGPR in the search loop
 struct NnGrid {
   float xmin, ymin, inv_c;
@@ -623,8 +633,8 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
   float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f}, pbnd = 0.f;
   if (slot >= 0 && slot < n) {
     const int i = slot;
-    pa[0] = ld_u32(mod, 3 * i); pa[1] = ld_u32(mod, 3 * i + 1); pa[2] = ld_u32(mod, 3 * i + 2);
-    pb[0] = ld_u32(ref, 3 * i); pb[1] = ld_u32(ref, 3 * i + 1); pb[2] = ld_u32(ref, 3 * i + 2);
+    { const F3 v3_ = ld3_u32(mod, i); pa[0] = v3_.x; pa[1] = v3_.y; pa[2] = v3_.z; }
+    { const F3 v3_ = ld3_u32(ref, i); pb[0] = v3_.x; pb[1] = v3_.y; pb[2] = v3_.z; }
     if (Ropt) pbnd = ld_u32(bnd, i);
   }
   for (int t = 0; t < ntiles; ++t) {
@@ -636,8 +646,8 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
       const float bprev = pbnd;
       {
         const int in = min(i + TQ, n - 1);                // clamped: unused past the end (this thread owns row i + TQ)
-        pa[0] = ld_u32(mod, 3 * in); pa[1] = ld_u32(mod, 3 * in + 1); pa[2] = ld_u32(mod, 3 * in + 2);
-        pb[0] = ld_u32(ref, 3 * in); pb[1] = ld_u32(ref, 3 * in + 1); pb[2] = ld_u32(ref, 3 * in + 2);
+        { const F3 v3_ = ld3_u32(mod, in); pa[0] = v3_.x; pa[1] = v3_.y; pa[2] = v3_.z; }
+        { const F3 v3_ = ld3_u32(ref, in); pb[0] = v3_.x; pb[1] = v3_.y; pb[2] = v3_.z; }
         if (Ropt) pbnd = ld_u32(bnd, in);
       }
       if (i < n) {
@@ -776,10 +786,11 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
       const NnGrid G = nn_grid(S);
       int i = threadIdx.x;
       float qx = 0.f, qy = 0.f, qz = 0.f, qb = 0.f;
-      if (i < n_model) { qx = ld_u32(mod, 3 * i); qy = ld_u32(mod, 3 * i + 1); qz = ld_u32(mod, 3 * i + 2); qb = ld_u32(bnd, i); }
+      if (i < n_model) { const F3 q3 = ld3_u32(mod, i); qx = q3.x; qy = q3.y; qz = q3.z; qb = ld_u32(bnd, i); }
       for (; i < n_model; i += ICP_BS) {
         const int in = min(i + ICP_BS, n_model - 1);       // clamped: unused past the end
-        const float nqx = ld_u32(mod, 3 * in), nqy = ld_u32(mod, 3 * in + 1), nqz = ld_u32(mod, 3 * in + 2), nqb = ld_u32(bnd, in);
+        const F3 nq3 = ld3_u32(mod, in);
+        const float nqx = nq3.x, nqy = nq3.y, nqz = nq3.z, nqb = ld_u32(bnd, in);
         int cx0, cx1, cy0, cy1, j = -1;
         float d = NAN;
         if (nn_ranges(G, qx, qy, qz, thr, r_thr, qb, &cx0, &cx1, &cy0, &cy1))
@@ -817,20 +828,22 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
       float m1[3] = {0.f, 0.f, 0.f}, r1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
       if (slot >= 0) {
         const int i0 = slot, i1 = TQ + slot;
-        if (i0 < rows) { j1 = ld_u32(nn, i0); m1[0] = ld_u32(mod, 3 * i0); m1[1] = ld_u32(mod, 3 * i0 + 1); m1[2] = ld_u32(mod, 3 * i0 + 2); }
-        if (i1 < rows) { j2 = ld_u32(nn, i1); m2[0] = ld_u32(mod, 3 * i1); m2[1] = ld_u32(mod, 3 * i1 + 1); m2[2] = ld_u32(mod, 3 * i1 + 2); }
+        if (i0 < rows) { j1 = ld_u32(nn, i0); { const F3 v3_ = ld3_u32(mod, i0); m1[0] = v3_.x; m1[1] = v3_.y; m1[2] = v3_.z; } }
+        if (i1 < rows) { j2 = ld_u32(nn, i1); { const F3 v3_ = ld3_u32(mod, i1); m2[0] = v3_.x; m2[1] = v3_.y; m2[2] = v3_.z; } }
         const int g = max(j1, 0);
-        r1[0] = ld_u32(ref, 3 * g); r1[1] = ld_u32(ref, 3 * g + 1); r1[2] = ld_u32(ref, 3 * g + 2);
+        { const F3 v3_ = ld3_u32(ref, g); r1[0] = v3_.x; r1[1] = v3_.y; r1[2] = v3_.z; }
       }
       for (int t = 0; t < ntiles; ++t) {
         if (slot >= 0) {
           const int i3 = min((t + 2) * TQ + slot, rows - 1);     // clamped: unused past the end
           const bool in3 = (t + 2) * TQ + slot < rows;
           int j3 = ld_u32(nn, i3);
-          const float m3[3] = {ld_u32(mod, 3 * i3), ld_u32(mod, 3 * i3 + 1), ld_u32(mod, 3 * i3 + 2)};
+          const F3 m3v = ld3_u32(mod, i3);
+          const float m3[3] = {m3v.x, m3v.y, m3v.z};
           j3 = in3 ? j3 : -1;
           const int g = max(j2, 0);
-          const float r2[3] = {ld_u32(ref, 3 * g), ld_u32(ref, 3 * g + 1), ld_u32(ref, 3 * g + 2)};
+          const F3 r2v = ld3_u32(ref, g);
+          const float r2[3] = {r2v.x, r2v.y, r2v.z};
           const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f
           float (*tile)[ICP_TS] = S.prod[t & 1];
 #pragma unroll
