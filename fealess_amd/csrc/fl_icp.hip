@@ -378,6 +378,24 @@ __device__ __forceinline__ float chain_tile(const float *col, int rows, float ac
   return acc;
 }
 
+// uniform base + 32-bit unsigned byte offset: one VGPR per address (global_load ... v_off, s[base]) instead of a
+// sign-extended 64-bit pointer pair -- the search keeps 24 addresses in flight
+template <typename T>
+__device__ __forceinline__ T ld_u32(const T *__restrict__ base, int idx)
+{
+  return *(const T *)((const char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
+}
+
+// one 12-byte load (global_load_dwordx3) for a point instead of three dword loads: the phases are bound by the
+// number of vector-memory instructions as much as by anything else
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
+{
+  F3 v;
+  __builtin_memcpy(&v, (const char *)base + (size_t)((unsigned)i * 12u), 12);
+  return v;
+}
+
 // ---- uniform x/y grid over the reference cloud --------------------------------------------------
 __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
 {
@@ -392,7 +410,8 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   // bounding box of the finite points
   float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
   for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
-    const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
+    const F3 p3 = ld3_u32(ref, i);
+    const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
       xmin = fminf(xmin, x);
       xmax = fmaxf(xmax, x);
@@ -448,7 +467,8 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
-    const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
+    const F3 p3 = ld3_u32(ref, i);
+    const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z))
       atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
   }
@@ -470,7 +490,8 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = cell_start[i];
   __syncthreads();
   for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
-    const float x = ref[3 * i], y = ref[3 * i + 1], z = ref[3 * i + 2];
+    const F3 p3 = ld3_u32(ref, i);
+    const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
       const int slot = atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
       sref[slot] = make_float4(x, y, z, __int_as_float(i));
@@ -484,24 +505,6 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
 // `bnd` is an upper bound on the distance to SOME reference point (last iteration's partner plus how far the
 // query moved since, see l2dist_phase): it only shrinks the visited area -- every point within that distance
 // is still seen, so the result is the exact nearest neighbour.  r_thr = sqrtf(thr).
-// uniform base + 32-bit unsigned byte offset: one VGPR per address (global_load ... v_off, s[base]) instead of a
-// sign-extended 64-bit pointer pair -- the search keeps 24 addresses in flight
-template <typename T>
-__device__ __forceinline__ T ld_u32(const T *__restrict__ base, int idx)
-{
-  return *(const T *)((const char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
-}
-
-// one 12-byte load (global_load_dwordx3) for a point instead of three dword loads: the phases are bound by the
-// number of vector-memory instructions as much as by anything else
-struct F3 { float x, y, z; };
-__device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
-{
-  F3 v;
-  __builtin_memcpy(&v, (const char *)base + (size_t)((unsigned)i * 12u), 12);
-  return v;
-}
-
 // the grid parameters as wave-uniform scalars (SGPRs): read from LDS they would each cost a VGPR in the search loop
 struct NnGrid {
   float xmin, ymin, inv_c;
