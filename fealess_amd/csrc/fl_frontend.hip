@@ -215,57 +215,112 @@ int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, si
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pyrdown_bgr(const uint8_t *__restrict__ src_, size_t in_stride,
-                                                     uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+// cv::pyrDown.  The stage is bound by vector-memory instructions, whose cost on gfx950 depends on alignment and lane
+// stride much more than on width (tools/dev/ldwidth.hip: a 16-byte load costs ~30 cycles per wave when 4-byte
+// aligned, ~70 at byte alignment or a 6-byte lane stride; a byte load at stride 5 ~25).  So:
+//   k_pyrdown_pairs   interior: one thread makes TWO adjacent output pixels; their 7 source pixels are 21 bytes
+//                     inside the 4-byte aligned 24-byte window starting at 12 x' - 8 -> one 16-byte + one 8-byte
+//                     aligned load per source row, three 2-byte stores per thread
+//   k_pyrdown_general any pixel, REFLECT_101 taps fetched one by one: the two border pixel pairs of every row
+//                     (second, tiny grid) and whole images that are too small for the pair kernel
+__device__ __forceinline__ void pyrdown_general_px(const uint8_t *__restrict__ src, int w, int h, int x, int y, uint8_t *o)
 {
-  const int dw = w / 2, dh = h / 2;
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (x >= dw || y >= dh) return;
-  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
-  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
   const int k[5] = {1, 4, 6, 4, 1};
   int acc0 = 0, acc1 = 0, acc2 = 0;
-  // interior columns: the 5 taps are 15 contiguous bytes -> one 16-byte load per source row
-  const bool wide = 2 * x - 2 >= 0 && 2 * x + 2 <= w - 1 && 3 * (2 * x - 2) + 16 <= 3 * w;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int yy = reflect101(2 * y + j - 2, h);
     int r0 = 0, r1 = 0, r2 = 0;
-    if (wide) {
-      uint32_t wd[4];
-      __builtin_memcpy(wd, src + ((size_t)yy * w + 2 * x - 2) * 3, 16);
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int b0 = 3 * i, b1 = 3 * i + 1, b2 = 3 * i + 2;
-        r0 += k[i] * (int)((wd[b0 >> 2] >> (8 * (b0 & 3))) & 0xFFu);
-        r1 += k[i] * (int)((wd[b1 >> 2] >> (8 * (b1 & 3))) & 0xFFu);
-        r2 += k[i] * (int)((wd[b2 >> 2] >> (8 * (b2 & 3))) & 0xFFu);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int xx = reflect101(2 * x + i - 2, w);
-        const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
-        r0 += k[i] * p[0];
-        r1 += k[i] * p[1];
-        r2 += k[i] * p[2];
-      }
+    for (int i = 0; i < 5; ++i) {
+      const int xx = reflect101(2 * x + i - 2, w);
+      const uint8_t *p = src + ((size_t)yy * w + xx) * 3;
+      r0 += k[i] * p[0];
+      r1 += k[i] * p[1];
+      r2 += k[i] * p[2];
     }
     acc0 += k[j] * r0;
     acc1 += k[j] * r1;
     acc2 += k[j] * r2;
   }
-  uint8_t *o = dst + ((size_t)y * dw + x) * 3;
   o[0] = (uint8_t)((acc0 + 128) >> 8);
   o[1] = (uint8_t)((acc1 + 128) >> 8);
   o[2] = (uint8_t)((acc2 + 128) >> 8);
 }
 
+// border_only = 0: every pixel; 1: the pixels of the first and of the last pair of each row (x in {0, 1, dw-2, dw-1})
+__global__ __launch_bounds__(256) void k_pyrdown_general(const uint8_t *__restrict__ src_, size_t in_stride,
+                                                         uint8_t *__restrict__ dst_, size_t out_stride, int w, int h, int border_only)
+{
+  const int dw = w / 2, dh = h / 2;
+  int x, y;
+  if (border_only) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    y = t >> 2;
+    const int c = t & 3;
+    x = c < 2 ? c : dw - 4 + c;
+    if (y >= dh) return;
+  } else {
+    x = blockIdx.x * 32 + (threadIdx.x & 31);
+    y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= dw || y >= dh) return;
+  }
+  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  pyrdown_general_px(src, w, h, x, y, dst + ((size_t)y * dw + x) * 3);
+}
+
+__global__ __launch_bounds__(256) void k_pyrdown_pairs(const uint8_t *__restrict__ src_, size_t in_stride,
+                                                       uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+{
+  const int dw = w / 2, dh = h / 2;
+  const int xp = blockIdx.x * 32 + (threadIdx.x & 31) + 1, y = blockIdx.y * 8 + (threadIdx.x >> 5);   // pair index >= 1
+  if (xp > dw / 2 - 2 || y >= dh) return;                 // the last pair (and an odd last pixel) belong to the border grid
+  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  const int k[5] = {1, 4, 6, 4, 1};
+  int acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int yy = reflect101(2 * y + j - 2, h);
+    uint32_t wd[6];                                       // bytes 12 xp - 8 .. 12 xp + 15; source pixel 4 xp - 2 + t at byte 2 + 3 t
+    const uint8_t *p = src + (size_t)yy * w * 3 + 12 * xp - 8;
+    __builtin_memcpy(wd, p, 16);
+    __builtin_memcpy(wd + 4, p + 16, 8);
+#define SB(b) ((int)((wd[(b) >> 2] >> (8 * ((b) & 3))) & 0xFFu))
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const int r0 = SB(2 + ch) + 4 * SB(5 + ch) + 6 * SB(8 + ch) + 4 * SB(11 + ch) + SB(14 + ch);        // taps t = 0..4
+      const int r1 = SB(8 + ch) + 4 * SB(11 + ch) + 6 * SB(14 + ch) + 4 * SB(17 + ch) + SB(20 + ch);      // taps t = 2..6
+      acc[ch] += k[j] * r0;
+      acc[3 + ch] += k[j] * r1;
+    }
+#undef SB
+  }
+  uint16_t *o = (uint16_t *)(dst + ((size_t)y * dw + 2 * xp) * 3);         // 6 bytes at an even offset
+  uint32_t v[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) v[c] = (uint32_t)((acc[c] + 128) >> 8);
+  o[0] = (uint16_t)(v[0] | (v[1] << 8));
+  o[1] = (uint16_t)(v[2] | (v[3] << 8));
+  o[2] = (uint16_t)(v[4] | (v[5] << 8));
+}
+
 int fl_launch_pyrdown_bgr(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst, size_t out_stride,
                           int n_frames, int w, int h)
 {
-  dim3 grid((w / 2 + 31) / 32, (h / 2 + 7) / 8, n_frames);
-  hipLaunchKernelGGL(k_pyrdown_bgr, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+  const int dw = w / 2, dh = h / 2;
+  // the pair kernel stores 16-bit words: rows and frames of the output must start at even addresses
+  const bool pairs_ok = dw >= 8 && (dw & 1) == 0 && ((3 * dw) & 1) == 0 && (out_stride & 1) == 0 && (((size_t)dst) & 1) == 0;
+  if (!pairs_ok) {
+    dim3 grid((dw + 31) / 32, (dh + 7) / 8, n_frames);
+    hipLaunchKernelGGL(k_pyrdown_general, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h, 0);
+  } else {
+    dim3 grid((dw / 2 - 2 + 31) / 32, (dh + 7) / 8, n_frames);             // pairs 1 .. dw/2 - 2
+    hipLaunchKernelGGL(k_pyrdown_pairs, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+    dim3 gridb((4 * dh + 255) / 256, 1, n_frames);
+    hipLaunchKernelGGL(k_pyrdown_general, gridb, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h, 1);
+  }
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }
