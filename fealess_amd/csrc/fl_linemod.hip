@@ -295,12 +295,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
     const uint8_t *lm = ws + a.lm_off[m] + j0;
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const uint32_t *offs = a.offs + h.off_begin;
+    // A feature's 16 bytes start at an arbitrary byte.  A byte-aligned 16-byte load costs ~2.4x a 4-byte aligned one
+    // on gfx950 (tools/dev/ldwidth.hip) and this loop is bound by exactly those loads, so each feature is fetched as
+    // an aligned 16 + 4 bytes and shifted into place with four v_alignbyte (the misalignment is wave-uniform).
+    const unsigned lm_mis = (unsigned)(size_t)lm & 3u;    // same for every lane: j0 is a multiple of 16
     for (int k = 0; k < h.n_pad; k += 8) {
       uint4 v[8];
+      uint32_t e[8];
+      unsigned mis[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ld16(lm + offs[k + u]);
+      for (int u = 0; u < 8; ++u) {
+        const unsigned off = offs[k + u];
+        mis[u] = (lm_mis + off) & 3u;
+        const uint8_t *pa = lm + off - mis[u];             // 4-byte aligned
+        v[u] = *(const uint4 *)__builtin_assume_aligned(pa, 4);
+        e[u] = *(const uint32_t *)(pa + 16);
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w; }
+      for (int u = 0; u < 8; ++u) {
+        a0 += __builtin_amdgcn_alignbyte(v[u].y, v[u].x, mis[u]);
+        a1 += __builtin_amdgcn_alignbyte(v[u].z, v[u].y, mis[u]);
+        a2 += __builtin_amdgcn_alignbyte(v[u].w, v[u].z, mis[u]);
+        a3 += __builtin_amdgcn_alignbyte(e[u], v[u].w, mis[u]);
+      }
     }
     const uint32_t acc[4] = {a0, a1, a2, a3};
 #pragma unroll
