@@ -481,6 +481,23 @@ int fl_launch_quantized_normals(fl_context *ctx, const uint16_t *depth, size_t i
   return FL_OK;
 }
 
+// cv::resize INTER_NEAREST to half size (linemod.cpp:731): sx = min(floor(x * (1 / (dw / w))), w - 1).  For even w and h
+// that is src(2y, 2x); then one thread makes 4 output pixels from one aligned 8-byte load and stores one dword (the
+// one-pixel-per-thread version spent its time on byte loads and byte stores).  Other sizes take the general kernel.
+__global__ __launch_bounds__(256) void k_resize_nn_half4(const uint8_t *__restrict__ src_, size_t in_stride,
+                                                         uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
+{
+  const int dw = w / 2, dh = h / 2;
+  const int x4 = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (4 * x4 >= dw || y >= dh) return;
+  const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
+  uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
+  uint2 v;
+  __builtin_memcpy(&v, __builtin_assume_aligned(src + (size_t)(2 * y) * w + 8 * x4, 8), 8);
+  const uint32_t o = (v.x & 0xFFu) | ((v.x >> 8) & 0xFF00u) | ((v.y & 0xFFu) << 16) | ((v.y << 8) & 0xFF000000u);
+  *(uint32_t *)(dst + (size_t)y * dw + 4 * x4) = o;
+}
+
 __global__ __launch_bounds__(256) void k_resize_nn_half(const uint8_t *__restrict__ src_, size_t in_stride,
                                                         uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
 {
@@ -489,7 +506,6 @@ __global__ __launch_bounds__(256) void k_resize_nn_half(const uint8_t *__restric
   if (x >= dw || y >= dh) return;
   const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
   uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
-  // cv::resize INTER_NEAREST (linemod.cpp:731): sx = min(floor(x * (1 / (dw / w))), w - 1)
   int sx = (int)floor(x * (1.0 / ((double)dw / w))), sy = (int)floor(y * (1.0 / ((double)dh / h)));
   sx = min(sx, w - 1);
   sy = min(sy, h - 1);
@@ -499,8 +515,15 @@ __global__ __launch_bounds__(256) void k_resize_nn_half(const uint8_t *__restric
 int fl_launch_resize_nn_half(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst, size_t out_stride,
                              int n_frames, int w, int h)
 {
-  dim3 grid((w / 2 + 63) / 64, (h / 2 + 3) / 4, n_frames);
-  hipLaunchKernelGGL(k_resize_nn_half, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+  // even sizes: 1 / ((w/2) / w) == 2 exactly, so the source pixel is (2y, 2x); w % 8 == 0 keeps the 8-byte loads aligned
+  const bool fast = (w % 8) == 0 && (h % 2) == 0 && ((in_stride | out_stride) & 7) == 0 && ((((size_t)src) | ((size_t)dst)) & 7) == 0;
+  if (fast) {
+    dim3 grid((w / 8 + 63) / 64, (h / 2 + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_resize_nn_half4, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+  } else {
+    dim3 grid((w / 2 + 63) / 64, (h / 2 + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_resize_nn_half, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
+  }
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }
