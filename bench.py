@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--levels", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1280, help="frames per step per GPU (1280 = 5 ICP workgroups on each of the 256 CUs)")
     ap.add_argument("--icp-iters", type=int, default=20)
-    ap.add_argument("--icp-mode", choices=["parity", "fast"], default="parity")
+    ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -171,7 +171,7 @@ def main():
     bptr = [d_bgr.data_ptr() + i * 640 * 480 * 3 for i in range(B)]
     dptr = [d_depth.data_ptr() + i * 640 * 480 * 2 for i in range(B)]
     K = (608.0, 608.0, 320.0, 240.0)
-    mode = L.FL_ICP_PARITY if args.icp_mode == "parity" else L.FL_ICP_FAST
+    mode = {"parity": L.FL_ICP_PARITY, "fast": L.FL_ICP_FAST, "plane": L.FL_ICP_POINT_TO_PLANE}[args.icp_mode]
     params = L.RecognitionParams(75.0, args.icp_iters, -1.0, FORCE_ALL_ITERS, mode)
 
     def step():

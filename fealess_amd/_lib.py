@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libfealess_hip.so")
 FL_OK = 0
 FL_ERR_INVALID, FL_ERR_HIP, FL_ERR_ASSERT, FL_ERR_OVERFLOW, FL_ERR_NO_DEVICE, FL_ERR_STATE, FL_ERR_NO_TEMPLATE = -1, -2, -3, -4, -5, -6, -7
 FL_MEM_HOST, FL_MEM_DEVICE = 0, 1
-FL_ICP_PARITY, FL_ICP_FAST = 0, 1
+FL_ICP_PARITY, FL_ICP_FAST, FL_ICP_POINT_TO_PLANE = 0, 1, 2
 
 
 class Feature(C.Structure):
@@ -92,6 +92,7 @@ SIGNATURES = {
     "fl_build_linear_memories": (_I, [_P, _P, _I, _I, _I, _P, _I]),
     "fl_depth_to_3d": (_I, [_P, _P, _I, _I, _D, _D, _D, _D, _P, _I]),
     "fl_icp": (_I, [_P, _P, _I, _P, _I, _I, _F, _F, _I, _I, C.POINTER(IcpResult)]),
+    "fl_icp_point_to_plane": (_I, [_P, _P, _P, _I, _P, _I, _I, _F, _F, _I, C.POINTER(IcpResult)]),
     "fl_detection": (_I, [_P, _P, _P, _I, _I, C.POINTER(Intrinsics), C.POINTER(_I), C.POINTER(_I), _I, _F, _F,
                           C.POINTER(_F), C.POINTER(_F), _I, _I, C.POINTER(DetectionResult)]),
     "fl_match_quantized": (_I, [_P, C.POINTER(_P), _I, _F, _P, _I, C.POINTER(_I)]),

@@ -132,6 +132,18 @@ class Context:
                                    dist_diff_thr, mode, L.FL_MEM_HOST, C.byref(res)))
         return icp_result_to_dict(res)
 
+    def icp_point_to_plane(self, ref, ref_normals, model, icp_it_thr=4, dist_mean_thr=0.0, dist_diff_thr=0.0):
+        """FL_ICP_POINT_TO_PLANE on caller-supplied clouds (no reference counterpart)."""
+        ref = np.ascontiguousarray(ref, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(ref_normals, np.float32).reshape(-1, 3)
+        if len(nrm) != len(ref):
+            raise ValueError("ref_normals must have one normal per reference point")
+        model = np.ascontiguousarray(model, np.float32).reshape(-1, 3)
+        res = L.IcpResult()
+        self.check(self.lib.fl_icp_point_to_plane(self.h, _ptr(ref), _ptr(nrm), len(ref), _ptr(model), len(model),
+                                                  icp_it_thr, dist_mean_thr, dist_diff_thr, L.FL_MEM_HOST, C.byref(res)))
+        return icp_result_to_dict(res)
+
     def detection(self, model_depth_mm, scene_depth_mm, K, rect_model, rect_ref, icp_it_thr, dist_mean_thr,
                   dist_diff_thr, r_match, t_match, mode=L.FL_ICP_PARITY):
         md = np.ascontiguousarray(model_depth_mm, np.uint16)

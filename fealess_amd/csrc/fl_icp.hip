@@ -16,6 +16,8 @@
 //     float32 chain accumulated in the reference's order by its own lane; dropped pairs add an
 //     exact +0.0f so the chain is branch-free.  Bit-identical to the reference's arithmetic.
 //   * FL_ICP_FAST: fp64 per-thread partials + fixed-shape tree, rounded once to float32.
+//   * FL_ICP_POINT_TO_PLANE (no reference counterpart): NN pairs from the first
+//     iteration on, 27 fp64 sums of the linearised point-to-plane system, 6x6 Cholesky + Rodrigues.
 // Nearest neighbours: the reference's FLANN kd-tree (exact 1-NN, eps 0) is replaced by a uniform
 // x/y cell grid over the static reference cloud built once per frame; a query only visits the
 // cells within sqrt(3*dist_mean) because farther neighbours are discarded anyway
@@ -55,8 +57,9 @@
 //   nn     n x i32    nearest reference index j of model point i (kept pair: j, dropped: -1)
 //   bnd    n x f32    upper bound on the distance from model point i to its nearest reference point
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid
+//   nrm   n x 3 f32   unit normals of the reference cloud, index order (FL_ICP_POINT_TO_PLANE only; 0 = unknown)
 struct IcpWsLayout {
-  size_t ref, mod, sref, nn, bnd, cell_start, cell_cur, total;
+  size_t ref, mod, sref, nn, bnd, cell_start, cell_cur, nrm, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -72,6 +75,7 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.bnd = o; o = al256(o + 4 * nn);
   L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
   L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
+  L.nrm = o; o = al256(o + 12 * nn);
   L.total = o;
   return L;
 }
@@ -118,7 +122,7 @@ struct IcpShared {
   float xmin, ymin, inv_c;
   int GX, GY, nsorted;
   float sums[16];
-  double dsum[ICP_BS / 64][16];   // [wave][scalar]
+  double dsum[ICP_BS / 64][32];   // [wave][scalar]
   int iscan[ICP_BS / 64 + 1];
   int ibase;
   float fred[4][ICP_BS / 64];
@@ -727,7 +731,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
   float4 *sref = (float4 *)(wsb + L.sref);
   int *nn = (int *)(wsb + L.nn);
   float *bnd = (float *)(wsb + L.bnd);
+  const float *nrm = (const float *)(wsb + L.nrm);
   int *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
+  constexpr bool plane = MODE == FL_ICP_POINT_TO_PLANE;
+  constexpr int NSUM = plane ? 27 : 15;
 
   if (threadIdx.x == 0) {
     for (int i = 0; i < 9; ++i) S.R[i] = 0.f;           // cv::Matx33f R; cv::Vec3f T; zero-initialised
@@ -769,7 +776,9 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     if (threadIdx.x == 0) S.go = (S.dist_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);   // :684
     __syncthreads();
     if (!S.go) break;
-    if (threadIdx.x == 0) { ++S.iter; S.thr = 3 * S.dist_mean; }
+    // point-to-plane gates pairs at distance 3*dist_mean; the reference compares the SQUARED distance
+    // with 3*dist_mean (Q9), which parity/fast keep
+    if (threadIdx.x == 0) { ++S.iter; S.thr = plane ? (3 * S.dist_mean) * (3 * S.dist_mean) : 3 * S.dist_mean; }
     __syncthreads();
     const int iter = S.iter;
     const float thr = S.thr;
@@ -777,10 +786,11 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     constexpr bool parity = MODE == FL_ICP_PARITY;
     constexpr int mode = MODE;
     int kept = 0;
-    double ds[15];
+    const bool index_pairs = iter == 1 && !plane;       // :700-704
+    double ds[NSUM];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) ds[k] = 0.0;
-    if (iter > 1) {
+    for (int k = 0; k < NSUM; ++k) ds[k] = 0.0;
+    if (!index_pairs) {
       // Phase A1 -- PointsCorresponding (:193-279): all four waves search.  bnd[i] (distance to the partner found
       // last time plus the motion since; initially the index pair) bounds the search radius, so a converging
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.  Every load
@@ -802,7 +812,22 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
         if (keep) ++kept;
         nn[i] = keep ? j : -1;
         if (j >= 0) bnd[i] = sqrtf(d);                    // else: the old partner is still within qb
-        if (!parity && keep) {
+        if (plane && keep) {
+          // linearised point-to-plane: residual e = n.(m - r), Jacobian row J = [m x n, n] wrt (omega, t);
+          // ds = upper triangle of sum J J^T (21) followed by sum J e (6)
+          const F3 rv = ld3_u32(ref, j), nv = ld3_u32(nrm, j);
+          const double n0 = nv.x, n1 = nv.y, n2 = nv.z, m0 = qx, m1 = qy, m2 = qz;
+          const double J[6] = {m1 * n2 - m2 * n1, m2 * n0 - m0 * n2, m0 * n1 - m1 * n0, n0, n1, n2};
+          const double e = n0 * (m0 - (double)rv.x) + n1 * (m1 - (double)rv.y) + n2 * (m2 - (double)rv.z);
+          int q = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) ds[q++] += J[a] * J[b];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) ds[21 + a] += J[a] * e;
+        }
+        if (!parity && !plane && keep) {
           const float m[3] = {qx, qy, qz}, r[3] = {ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]};
 #pragma unroll
           for (int a = 0; a < 3; ++a)
@@ -821,7 +846,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     // in row order -- getMean (:8-25) and the covariance loop (:731-735) as 15 float32 chains.
     const int TQ = parity ? ICP_BS - 64 : ICP_BS;
     const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
-    const int ntiles = (parity || iter == 1) ? (rows + TQ - 1) / TQ : 0;
+    const int ntiles = (parity || index_pairs) ? (rows + TQ - 1) / TQ : 0;
     float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
     if (parity && iter > 1) {
       // Two-deep register pipeline of the producers: a tile costs nn/mod loads (coalesced) and then the
@@ -913,7 +938,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
       acc = chain_tile(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, rows - (ntiles - 1) * TQ), acc);
     kept = block_sum_int(S, kept);
     TSTAMP(3);
-    const int ncm = iter == 1 ? n_model : kept, ncr = iter == 1 ? n_ref : kept;
+    const int ncm = index_pairs ? n_model : kept, ncr = index_pairs ? n_ref : kept;
     if (threadIdx.x == 0) S.n_corr = ncm;
     if (ncr < 3 || ncm < 3) {                            // :711-715
       __syncthreads();
@@ -925,8 +950,55 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
       if (threadIdx.x < 15) S.sums[threadIdx.x] = acc;
       __syncthreads();
     } else {
-      block_sum_double<15>(S, ds);
+      block_sum_double<NSUM>(S, ds);
     }
+    if (plane) {
+      if (threadIdx.x == 0) {
+        double A[6][6], x[6], tr = 0.0;
+        int q = 0;
+        for (int a = 0; a < 6; ++a)
+          for (int b = a; b < 6; ++b) A[a][b] = A[b][a] = S.dsum[0][q++];
+        for (int a = 0; a < 6; ++a) { x[a] = -S.dsum[0][21 + a]; tr += A[a][a]; }
+        bool ok = tr > 0.0 && tr < 1.0e300;
+        for (int a = 0; a < 6; ++a) A[a][a] += 1.0e-12 * tr;          // keeps a barely constrained direction finite
+        for (int c = 0; c < 6 && ok; ++c) {                            // Cholesky A = L L^T (lower triangle in place)
+          double d = A[c][c];
+          for (int k = 0; k < c; ++k) d -= A[c][k] * A[c][k];
+          if (!(d > 1.0e-13 * tr)) { ok = false; break; }              // a direction the pairs do not constrain
+          d = sqrt(d);
+          A[c][c] = d;
+          for (int r = c + 1; r < 6; ++r) {
+            double v = A[r][c];
+            for (int k = 0; k < c; ++k) v -= A[r][k] * A[c][k];
+            A[r][c] = v / d;
+          }
+        }
+        if (ok) {
+          for (int r = 0; r < 6; ++r) {                                // L y = b
+            double v = x[r];
+            for (int k = 0; k < r; ++k) v -= A[r][k] * x[k];
+            x[r] = v / A[r][r];
+          }
+          for (int r = 5; r >= 0; --r) {                               // L^T x = y
+            double v = x[r];
+            for (int k = r + 1; k < 6; ++k) v -= A[k][r] * x[k];
+            x[r] = v / A[r][r];
+          }
+          // Rodrigues: R = I + (sin t / t) K + ((1 - cos t) / t^2) K^2, K = [omega]x
+          const double wx = x[0], wy = x[1], wz = x[2], t2 = wx * wx + wy * wy + wz * wz, t = sqrt(t2);
+          const double sa = t > 1.0e-9 ? sin(t) / t : 1.0 - t2 / 6.0, sb = t > 1.0e-9 ? (1.0 - cos(t)) / t2 : 0.5 - t2 / 24.0;
+          const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+              double k2 = 0;
+              for (int k = 0; k < 3; ++k) k2 += K[i * 3 + k] * K[k * 3 + j];
+              S.Ropt[i * 3 + j] = (float)((i == j ? 1.0 : 0.0) + sa * K[i * 3 + j] + sb * k2);
+            }
+          for (int k = 0; k < 3; ++k) S.Topt[k] = (float)x[3 + k];
+        }
+        S.ok = ok && finite_all(S.Ropt, 9) && finite_all(S.Topt, 3);
+      }
+    } else
     if (threadIdx.x == 0) {
       float C[9], mc[3], rc[3];
       if (mode == FL_ICP_PARITY) {
@@ -984,8 +1056,39 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
 }
 
 // ---- detection() front half: crop back-projection + paired-valid compaction ----------------------
+// Unit surface normal at scene pixel (x, y) for FL_ICP_POINT_TO_PLANE (no reference counterpart): least-squares
+// depth gradient (zu, zv) over the (2r+1)^2 window -- on a complete window the fit decouples into
+// zu = sum du*z / sum du^2 -- then n = Pu x Pv of the back-projected surface P(u,v) = ((u-cx)/fx*z, (v-cy)/fy*z, z).
+// A window that leaves the image, holds a missing return or crosses a depth step (> 2 % + 2 mm of the centre
+// depth) gives n = 0: the point still takes part in the NN search but not in the 6x6 system.
+#define ICP_NRM_R 3
+__device__ __forceinline__ void scene_normal(const uint16_t *__restrict__ scene, int w, int h, int x, int y, float fx, float fy,
+                                             float cx, float cy, float *n)
+{
+  n[0] = n[1] = n[2] = 0.f;
+  if (x < ICP_NRM_R || y < ICP_NRM_R || x + ICP_NRM_R >= w || y + ICP_NRM_R >= h) return;
+  const float zc = (float)scene[(size_t)y * w + x], gate = 0.02f * zc + 2.0f;
+  float su = 0.f, sv = 0.f;
+  bool ok = zc > 0.f;
+  for (int dv = -ICP_NRM_R; dv <= ICP_NRM_R; ++dv)
+    for (int du = -ICP_NRM_R; du <= ICP_NRM_R; ++du) {
+      const float z = (float)scene[(size_t)(y + dv) * w + x + du];
+      ok = ok && z > 0.f && fabsf(z - zc) <= gate;
+      su += (float)du * z;
+      sv += (float)dv * z;
+    }
+  if (!ok) return;
+  const float s2 = (float)((2 * ICP_NRM_R + 1) * ICP_NRM_R * (ICP_NRM_R + 1) * (2 * ICP_NRM_R + 1) / 3);   // sum du^2 over the window
+  const float zu = su / s2, zv = sv / s2, X = (x - cx) / fx, Y = (y - cy) / fy;
+  const float pu[3] = {zc / fx + X * zu, Y * zu, zu}, pv[3] = {X * zv, zc / fy + Y * zv, zv};
+  const float c[3] = {pu[1] * pv[2] - pu[2] * pv[1], pu[2] * pv[0] - pu[0] * pv[2], pu[0] * pv[1] - pu[1] * pv[0]};
+  const float len = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  if (!(len > 0.f)) return;
+  n[0] = c[0] / len; n[1] = c[1] / len; n[2] = c[2] / len;
+}
+
 __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
-                           const int *rm, const int *rr, float *ref, float *mod)
+                           const int *rm, const int *rr, float *ref, float *mod, float *nrm)
 {
   const int cw = rm[2], ch = rm[3], np = cw * ch;
   const float inv_fx = 1.0f / a.fx, inv_fy = 1.0f / a.fy;                        // depth_to_3d.cpp:103-104
@@ -1022,6 +1125,11 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
       const int k = S.ibase + ex;
       ref[3 * k] = A[0]; ref[3 * k + 1] = A[1]; ref[3 * k + 2] = A[2];
       mod[3 * k] = B[0]; mod[3 * k + 1] = B[1]; mod[3 * k + 2] = B[2];
+      if (nrm) {
+        float nv[3];
+        scene_normal(scene, a.w, a.h, rr[0] + p % cw, rr[1] + p / cw, a.fx, a.fy, a.cx, a.cy, nv);
+        nrm[3 * k] = nv[0]; nrm[3 * k + 1] = nv[1]; nrm[3 * k + 2] = nv[2];
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) S.ibase += total;
@@ -1115,7 +1223,8 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       return;
     }
   }
-  const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod);
+  const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod,
+                             MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr);
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
   if (MODE == FL_ICP_PARITY) {
@@ -1213,6 +1322,7 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
 
 static int icp_threads(int) { return ICP_BS; }
 static size_t icp_lds_bytes() { return (sizeof(IcpShared) + 15) & ~(size_t)15; }
+static_assert(sizeof(IcpShared) + 16 <= 160 * 1024 / FL_ICP_WPE, "IcpShared must leave room for FL_ICP_WPE workgroups per CU");
 template <typename K>
 static int icp_launch_one(fl_context *ctx, K kern, int n_frames, const IcpArgs &a)
 {
@@ -1224,16 +1334,24 @@ static int icp_launch_one(fl_context *ctx, K kern, int n_frames, const IcpArgs &
 }
 static int icp_launch(fl_context *ctx, int n_frames, const IcpArgs &a)
 {
-  const bool fast = a.mode == FL_ICP_FAST;
-  if (a.job.kind == 2)
-    return fast ? icp_launch_one(ctx, k_icp_clouds<FL_ICP_FAST>, n_frames, a) : icp_launch_one(ctx, k_icp_clouds<FL_ICP_PARITY>, n_frames, a);
-  return fast ? icp_launch_one(ctx, k_icp_pipeline<FL_ICP_FAST>, n_frames, a) : icp_launch_one(ctx, k_icp_pipeline<FL_ICP_PARITY>, n_frames, a);
+  if (a.mode != FL_ICP_PARITY && a.mode != FL_ICP_FAST && a.mode != FL_ICP_POINT_TO_PLANE)
+    return fl_set_error(ctx, FL_ERR_INVALID, "unknown fl_icp_mode");
+  if (a.job.kind == 2) {
+    if (a.mode == FL_ICP_POINT_TO_PLANE) return icp_launch_one(ctx, k_icp_clouds<FL_ICP_POINT_TO_PLANE>, n_frames, a);
+    return a.mode == FL_ICP_FAST ? icp_launch_one(ctx, k_icp_clouds<FL_ICP_FAST>, n_frames, a)
+                                 : icp_launch_one(ctx, k_icp_clouds<FL_ICP_PARITY>, n_frames, a);
+  }
+  if (a.mode == FL_ICP_POINT_TO_PLANE) return icp_launch_one(ctx, k_icp_pipeline<FL_ICP_POINT_TO_PLANE>, n_frames, a);
+  return a.mode == FL_ICP_FAST ? icp_launch_one(ctx, k_icp_pipeline<FL_ICP_FAST>, n_frames, a)
+                               : icp_launch_one(ctx, k_icp_pipeline<FL_ICP_PARITY>, n_frames, a);
 }
 
-extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model, int icp_it_thr,
-                      float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem, fl_icp_result *res)
+static int icp_clouds(fl_context *ctx, const float *ref, const float *ref_normals, int n_ref, const float *model, int n_model,
+                      int icp_it_thr, float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem, fl_icp_result *res)
 {
   if (!ctx || !res || n_ref < 0 || n_model < 0 || (n_ref && !ref) || (n_model && !model)) return FL_ERR_INVALID;
+  if (icp_mode == FL_ICP_POINT_TO_PLANE && n_ref && !ref_normals)
+    return fl_set_error(ctx, FL_ERR_INVALID, "FL_ICP_POINT_TO_PLANE needs reference normals: use fl_icp_point_to_plane or fl_detection");
   FL_HIP(ctx, hipSetDevice(ctx->device));
   const int n_max = n_ref > n_model ? n_ref : n_model;
   const IcpWsLayout L = icp_layout(n_max);
@@ -1245,6 +1363,7 @@ extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float 
   const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (n_ref) FL_HIP(ctx, hipMemcpyAsync(wsb + L.ref, ref, 12 * (size_t)n_ref, kind, ctx->stream));
   if (n_model) FL_HIP(ctx, hipMemcpyAsync(wsb + L.mod, model, 12 * (size_t)n_model, kind, ctx->stream));
+  if (n_ref && ref_normals) FL_HIP(ctx, hipMemcpyAsync(wsb + L.nrm, ref_normals, 12 * (size_t)n_ref, kind, ctx->stream));
   IcpArgs a;
   memset(&a, 0, sizeof(a));
   a.ws = wsb;
@@ -1267,6 +1386,20 @@ extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float 
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *res = h->det.icp;
   return FL_OK;
+}
+
+extern "C" int fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model, int icp_it_thr,
+                      float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem, fl_icp_result *res)
+{
+  return icp_clouds(ctx, ref, nullptr, n_ref, model, n_model, icp_it_thr, dist_mean_thr, dist_diff_thr, icp_mode, mem, res);
+}
+
+extern "C" int fl_icp_point_to_plane(fl_context *ctx, const float *ref, const float *ref_normals, int n_ref, const float *model,
+                                     int n_model, int icp_it_thr, float dist_mean_thr, float dist_diff_thr, int mem,
+                                     fl_icp_result *res)
+{
+  return icp_clouds(ctx, ref, ref_normals, n_ref, model, n_model, icp_it_thr, dist_mean_thr, dist_diff_thr,
+                    FL_ICP_POINT_TO_PLANE, mem, res);
 }
 
 extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const uint16_t *scene_depth, int w, int h,

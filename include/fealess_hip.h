@@ -48,8 +48,18 @@ typedef enum { FL_MEM_HOST = 0, FL_MEM_DEVICE = 1 } fl_mem;
  *                   so results are bit-identical to the reference's arithmetic (ICP.cpp:8-25,
  *                   731-735, 68-111).  Default.
  *   FL_ICP_FAST   : the same sums as parallel fp64 tree reductions rounded once to float32
- *                   (more accurate than the reference, not bit-identical to it).            */
-typedef enum { FL_ICP_PARITY = 0, FL_ICP_FAST = 1 } fl_icp_mode;
+ *                   (more accurate than the reference, not bit-identical to it).
+ *   FL_ICP_POINT_TO_PLANE : opt-in extension with NO counterpart in the reference (SURVEY.md
+ *                   section 8f rank 4): every iteration (the first included) pairs each model point
+ *                   with its exact nearest reference point, gates the pair at distance
+ *                   <= 3*dist_mean, and minimises sum (n_j . (R m_i + t - r_j))^2 linearised in
+ *                   (omega, t): a 6x6 normal-equation system accumulated in fp64, solved by
+ *                   Cholesky, omega -> R by Rodrigues.  Reference-cloud normals n_j come from the
+ *                   organised scene depth (fl_detection / fl_recognize*) or from the caller
+ *                   (fl_icp_point_to_plane).  Loop control, dist_mean / px_ratio and the pose
+ *                   composition are those of icpCloudToCloud_Ex.  Validated against ground-truth
+ *                   poses of synthetic scenes, not against the reference.                     */
+typedef enum { FL_ICP_PARITY = 0, FL_ICP_FAST = 1, FL_ICP_POINT_TO_PLANE = 2 } fl_icp_mode;
 
 typedef struct fl_context fl_context;
 typedef struct fl_detector fl_detector;
@@ -176,6 +186,13 @@ int  fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int h, double
 int  fl_icp(fl_context *ctx, const float *ref, int n_ref, const float *model, int n_model,
             int icp_it_thr, float dist_mean_thr, float dist_diff_thr, int icp_mode, int mem,
             fl_icp_result *res);
+/* FL_ICP_POINT_TO_PLANE on caller-supplied clouds: ref_normals is n_ref*3 f32 (unit normals of the
+ * reference cloud; an all-zero normal excludes that point from the 6x6 system).  fl_icp itself
+ * refuses FL_ICP_POINT_TO_PLANE (FL_ERR_INVALID): it has no normals to work with.  No
+ * counterpart in the reference. */
+int  fl_icp_point_to_plane(fl_context *ctx, const float *ref, const float *ref_normals, int n_ref,
+                           const float *model, int n_model, int icp_it_thr, float dist_mean_thr,
+                           float dist_diff_thr, int mem, fl_icp_result *res);
 /* detection() (ICP/detection.cpp:11-254): two w*h u16 depth images in mm. res is host memory. */
 int  fl_detection(fl_context *ctx, const uint16_t *model_depth, const uint16_t *scene_depth,
                   int w, int h, const fl_intrinsics *K, const int rect_model[4],

@@ -221,3 +221,101 @@ def test_multi_hypothesis_topk_and_nms(ctx, oracle):
     assert det.nms(len(got), 0.0) == list(range(len(got)))          # nothing is closer than 0: every hypothesis survives
     assert det.nms(len(got), 1e9) in ([0], [win_exp[0]]) and len(det.nms(len(got), 1e9)) == 1
     det.close()
+
+
+# ---- FL_ICP_POINT_TO_PLANE (no reference counterpart, so no oracle) ----------------
+# Yardsticks: tests/p2plane_model.py (an independent numpy/scipy statement of the same algorithm) and the
+# ground-truth pose of the synthetic scene.
+def _angle_deg(Ra, Rb):
+    c = (np.trace(np.asarray(Ra, np.float64) @ np.asarray(Rb, np.float64).T) - 1) / 2
+    return float(np.degrees(np.arccos(np.clip(c, -1, 1))))
+
+
+def _bbox(m):
+    ys, xs = np.nonzero(m)
+    return int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1
+
+
+def _plane_case(seed, da, dt):
+    Rs, ts = synth.object_pose(tx=12, ty=-8, tz=655)
+    scene, _, ms = synth.render(640, 480, Rs, ts, seed=10 + seed)
+    Rm = synth.rot_z(da[0]) @ synth.rot_x(da[1]) @ synth.rot_y(da[2]) @ Rs
+    tm = ts + np.array(dt, float) + np.array([20.0, -12.0, 0.0])
+    model, _, mm = synth.render(640, 480, Rm, tm, seed=20 + seed, noise=False, background=False)
+    bs, bm = _bbox(ms), _bbox(mm)
+    cw = max(bs[2] - bs[0], bm[2] - bm[0]) + 8
+    ch = max(bs[3] - bs[1], bm[3] - bm[1]) + 8
+    return dict(scene=scene, model=model, Rs=Rs, ts=ts, Rm=Rm.astype(np.float32), tm=tm.astype(np.float32),
+                rect_ref=(bs[0] - 4, bs[1] - 4, cw, ch), rect_model=(bm[0] - 4, bm[1] - 4, cw, ch))
+
+
+PLANE_CASES = [((0.05, 0.03, -0.04), (6, -4, 5)), ((0.03, -0.05, 0.02), (-5, 3, -6)), ((-0.06, 0.02, 0.05), (3, 6, 4))]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_point_to_plane_detection_vs_model_and_ground_truth(ctx, seed):
+    import p2plane_model as P
+    c = _plane_case(seed, *PLANE_CASES[seed])
+    K = (608.0, 608.0, 320.0, 240.0)
+    args = (c["model"], c["scene"], K, c["rect_model"], c["rect_ref"], 20, 0.0, -3.0e38, c["Rm"], c["tm"])
+    got = ctx.detection(*args, L.FL_ICP_POINT_TO_PLANE)
+    exp = P.detection_point_to_plane(*args)
+    assert got["n_points"] == exp["n_points"] > 5000
+    assert got["icp"]["iters"] == exp["icp"]["iters"] == 20
+    # the kernel against the independent model: same pairs, same sums up to fp rounding
+    assert abs(got["icp"]["n_corr_last"] - exp["icp"]["n_corr_last"]) <= 5
+    assert _angle_deg(got["R_final"], exp["R_final"]) <= 0.02
+    assert np.abs(got["T_final"] - exp["T_final"]).max() <= 0.05
+    assert abs(got["icp"]["dist_mean"] - exp["icp"]["dist_mean"]) <= 1e-2
+    # both against the truth, and against the reference's point-to-point ICP on the same input
+    p2p = ctx.detection(*args, L.FL_ICP_PARITY)
+    e_plane, e_p2p = _angle_deg(got["R_final"], c["Rs"]), _angle_deg(p2p["R_final"], c["Rs"])
+    assert e_plane <= 1.0 and e_plane <= 0.5 * e_p2p, (e_plane, e_p2p)
+    assert np.linalg.norm(got["T_final"] - c["ts"]) <= 0.5
+    assert np.linalg.norm(got["T_final"] - c["ts"]) <= np.linalg.norm(p2p["T_final"] - c["ts"])
+
+
+def test_point_to_plane_on_clouds_and_argument_checks(ctx):
+    import p2plane_model as P
+    c = _plane_case(1, *PLANE_CASES[1])
+    K = (608.0, 608.0, 320.0, 240.0)
+    ref, mod, sx, sy = P.crop_pairs(c["model"], c["scene"], K, c["rect_model"], c["rect_ref"])
+    nrm = P.scene_normals(c["scene"], K, sx, sy)
+    assert (np.abs(np.linalg.norm(nrm, axis=1) - 1) < 1e-5).mean() > 0.8       # most points have a normal
+    mod = (mod + (ref.mean(0) - mod.mean(0))).astype(np.float32)
+    got = ctx.icp_point_to_plane(ref, nrm, mod, 15, 0.0, -3.0e38)
+    exp = P.icp_point_to_plane(ref, nrm, mod, 15, 0.0, -3.0e38)
+    assert got["iters"] == exp["iters"] == 15
+    assert _angle_deg(got["R"], exp["R"]) <= 0.02 and np.abs(got["T"] - exp["T"]).max() <= 0.2
+    # default thresholds stop early, exactly like icpCloudToCloud_Ex's loop control
+    got = ctx.icp_point_to_plane(ref, nrm, mod, 50, 0.5, 0.01)
+    exp = P.icp_point_to_plane(ref, nrm, mod, 50, 0.5, 0.01)
+    assert got["iters"] == exp["iters"] < 50
+    # all-zero normals constrain nothing: every iteration is skipped (counted), the pose stays the identity
+    r = ctx.icp_point_to_plane(ref, np.zeros_like(nrm), mod, 4, 0.0, -3.0e38)
+    assert r["iters"] == 4 and np.array_equal(r["R"], np.eye(3, dtype=np.float32)) and not r["T"].any()
+    # fl_icp has no normals to offer
+    with pytest.raises(api.FealessError) as e:
+        ctx.icp_cloud_to_cloud_ex(ref, mod, 4, 0.0, 0.0, L.FL_ICP_POINT_TO_PLANE)
+    assert e.value.code == L.FL_ERR_INVALID
+    with pytest.raises(api.FealessError):
+        ctx.icp_cloud_to_cloud_ex(ref, mod, 4, 0.0, 0.0, 7)
+    r = ctx.icp_point_to_plane(ref[:2], nrm[:2], mod[:2], 4)
+    assert r["dist_mean"] == -1.0 and r["iters"] == 0
+
+
+def test_point_to_plane_recognition_improves_the_pose(ctx, oracle):
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=3, n_views=5, n_random=10)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480, max_batch=2)
+    frames_b, frames_d = [sc["bgr"], sc["bgr"]], [sc["depth"], sc["depth"]]
+    p2p = det.recognize_batch(frames_b, frames_d, sc["K"], 75.0, 20, 0.0, -3.0e38, L.FL_ICP_PARITY)
+    pl = det.recognize_batch(frames_b, frames_d, sc["K"], 75.0, 20, 0.0, -3.0e38, L.FL_ICP_POINT_TO_PLANE)
+    for a, b in zip(p2p, pl):
+        assert a["found"] == b["found"] == 1 and a["best"] == b["best"]        # the LINEMOD half is untouched
+        ea, eb = _angle_deg(a["pose"][:3, :3], sc["R_true"]), _angle_deg(b["pose"][:3, :3], sc["R_true"])
+        assert eb <= max(1.0, 0.75 * ea), (ea, eb)
+        assert np.linalg.norm(b["pose"][:3, 3] - sc["t_true"]) <= max(1.0, np.linalg.norm(a["pose"][:3, 3] - sc["t_true"]))
+    assert np.array_equal(pl[0]["pose"], pl[1]["pose"])
+    det.close()

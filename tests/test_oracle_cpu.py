@@ -446,3 +446,28 @@ def test_filters_and_nn_pinned_against_scipy(oracle):
     d, j = sp.cKDTree(ref.astype(np.float64)).query(moved.astype(np.float64))
     kept = int((d * d <= 3.0 * float(dm1)).sum())
     assert abs(int(r["trace"][1][0]) - kept) <= 1                 # <= 1: a pair exactly on the float32 / float64 boundary
+
+
+def test_point_to_plane_model_recovers_ground_truth():
+    """tests/p2plane_model.py is the yardstick of the GPU's FL_ICP_POINT_TO_PLANE tests: check the yardstick itself
+    against the synthetic scene's true pose (the mode has no reference counterpart, hence no oracle)."""
+    import p2plane_model as P
+    from fealess_amd import synth
+    Rs, ts = synth.object_pose(tx=12, ty=-8, tz=655)
+    scene, _, ms = synth.render(640, 480, Rs, ts, seed=10)
+    Rm = synth.rot_z(0.05) @ synth.rot_x(0.03) @ synth.rot_y(-0.04) @ Rs
+    tm = ts + np.array([26.0, -16.0, 5.0])
+    model, _, mm = synth.render(640, 480, Rm, tm, seed=20, noise=False, background=False)
+    ys, xs = np.nonzero(ms)
+    ym, xm = np.nonzero(mm)
+    cw = max(xs.max() - xs.min(), xm.max() - xm.min()) + 9
+    ch = max(ys.max() - ys.min(), ym.max() - ym.min()) + 9
+    out = P.detection_point_to_plane(model, scene, (608.0, 608.0, 320.0, 240.0), (int(xm.min()) - 4, int(ym.min()) - 4, int(cw), int(ch)),
+                                     (int(xs.min()) - 4, int(ys.min()) - 4, int(cw), int(ch)), 20, 0.0, -3.0e38,
+                                     Rm.astype(np.float32), tm.astype(np.float32))
+    c = (np.trace(out["R_final"].astype(np.float64) @ Rs.T) - 1) / 2
+    assert np.degrees(np.arccos(np.clip(c, -1, 1))) < 1.0
+    assert np.linalg.norm(out["T_final"] - ts) < 0.5
+    n = out["normals"]
+    has = np.linalg.norm(n, axis=1) > 0
+    assert has.mean() > 0.8 and np.abs(np.linalg.norm(n[has], axis=1) - 1).max() < 1e-5
