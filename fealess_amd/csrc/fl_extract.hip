@@ -11,8 +11,9 @@
 //   k_depth_keys         score / label_count -> sort keys
 //   k_bitonic_step       global-memory bitonic sort of the keys: (score desc, raster order asc) is exactly what
 //                        std::stable_sort with Candidate::operator< yields
-//   k_select_scattered   the greedy, inherently sequential selection: one wave, the chosen features live one per
-//                        lane (LDS beyond 64), a candidate is tested against all of them with one ballot
+//   k_select_scattered   the greedy selection, sequential in its result but not in its work: every candidate keeps its
+//                        squared distance to the nearest chosen feature, the walk to the next passing candidate is a
+//                        workgroup-wide min (1024 threads)
 #include "fl_internal.h"
 #include <limits.h>
 #include <utility>
@@ -147,15 +148,22 @@ __global__ __launch_bounds__(256) void k_bitonic_step(unsigned long long *keys, 
   }
 }
 
-// selectScatteredFeatures (:135-164).  One wave; out[] doubles as the list of chosen features.
-__global__ __launch_bounds__(64) void k_select_scattered(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ labels_img,
-                                                         int w, int num_features, int depth_mode, int total_px,
-                                                         ExtractCounters *cnt, fl_feature *__restrict__ out)
+// selectScatteredFeatures (:135-164).  The reference re-tests every candidate against every chosen feature on every
+// pass (~candidates x features x passes distance tests, with the distance dropping by one per pass).  Here each
+// candidate carries mind2 = its squared distance to the nearest chosen feature so far, so `keep` is one compare,
+// an accepted feature is folded into mind2 with one test per candidate, and the sequential walk "next candidate
+// at or after i that passes" is a workgroup-wide min.  Same features in the same order.  Thread t owns candidates
+// t, t + 1024, ...: xy / mind2 (global scratch) are only ever touched by their owner, so no fences are needed.
+#define SEL_BS 1024
+__global__ __launch_bounds__(SEL_BS) void k_select_scattered(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ labels_img,
+                                                             int w, int num_features, int depth_mode, int total_px,
+                                                             ExtractCounters *cnt, fl_feature *__restrict__ out,
+                                                             uint32_t *__restrict__ xy, int *__restrict__ mind2)
 {
-  __shared__ int sx[1024], sy[1024];                     // chosen features (LDS: in-order within the wave)
-  const int lane = threadIdx.x;
+  __shared__ int s_min[SEL_BS / 64];
+  const int tid = threadIdx.x;
   const int n = cnt->n_cand;
-  if (n < num_features || num_features > 1024) { if (lane == 0) cnt->n_out = -1; return; }   // "We require a certain number of features"
+  if (n < num_features || num_features > 1024) { if (tid == 0) cnt->n_out = -1; return; }   // "We require a certain number of features"
   float distance;
   if (depth_mode) {
     const float area = cnt->area > 0 || depth_mode == 2 ? (float)cnt->area : (float)total_px;
@@ -164,33 +172,58 @@ __global__ __launch_bounds__(64) void k_select_scattered(const unsigned long lon
     distance = (float)(n / num_features + 1);                                    // :503-505
   }
   float distance_sq = distance * distance;
-  int nf = 0, i = 0;
+  for (int c = tid; c < n; c += SEL_BS) {
+    const unsigned raster = (unsigned)(keys[c] & 0xFFFFFFFFull);
+    xy[c] = (raster % (unsigned)w) | ((raster / (unsigned)w) << 16);
+    mind2[c] = INT_MAX;                                    // no feature chosen yet: every test passes
+  }
+  int nf = 0, i = 0, fx = 0, fy = 0;
+  bool fold = false;
   while (nf < num_features) {
-    const int raster = (int)(keys[i] & 0xFFFFFFFFull);
-    const int cx = raster % w, cy = raster / w;
-    bool lane_ok = true;                                   // this lane's chosen features are far enough
-    for (int j = lane; j < nf; j += 64) {
-      const int dx = cx - sx[j], dy = cy - sy[j];
-      lane_ok = lane_ok && ((float)(dx * dx + dy * dy) >= distance_sq);
-    }
-    const bool keep = __all(lane_ok);
-    if (keep) {
-      if (lane == 0) {
-        sx[nf] = cx;
-        sy[nf] = cy;
-        out[nf].x = cx;
-        out[nf].y = cy;
-        out[nf].label = ex_label(labels_img[raster]);
+    int mine = INT_MAX;                                    // my first candidate >= i that is far enough from all features
+    for (int c = tid; c < n; c += SEL_BS) {
+      int m = mind2[c];
+      if (fold) {
+        const uint32_t u = xy[c];
+        const int dx = (int)(u & 0xFFFFu) - fx, dy = (int)(u >> 16) - fy;
+        m = min(m, dx * dx + dy * dy);
+        mind2[c] = m;
       }
-      ++nf;
+      if (c >= i && (float)m >= distance_sq) mine = min(mine, c);
     }
-    if (++i == n) {                                        // start over with a relaxed distance
+    fold = false;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) mine = min(mine, __shfl_xor(mine, sft, 64));
+    __syncthreads();                                       // s_min of the previous round has been read by everyone
+    if ((tid & 63) == 0) s_min[tid >> 6] = mine;
+    __syncthreads();
+    int p = INT_MAX;
+#pragma unroll
+    for (int k = 0; k < SEL_BS / 64; ++k) p = min(p, s_min[k]);
+    if (p == INT_MAX) {                                    // nobody up to the end of the list: relax and start over
+      i = 0;
+      distance -= 1.0f;
+      distance_sq = distance * distance;
+      continue;
+    }
+    const int raster = (int)(keys[p] & 0xFFFFFFFFull);
+    fx = raster % w;
+    fy = raster / w;
+    if (tid == 0) {
+      out[nf].x = fx;
+      out[nf].y = fy;
+      out[nf].label = ex_label(labels_img[raster]);
+    }
+    fold = true;
+    ++nf;
+    i = p + 1;
+    if (i == n) {                                          // start over with a relaxed distance
       i = 0;
       distance -= 1.0f;
       distance_sq = distance * distance;
     }
   }
-  if (lane == 0) cnt->n_out = nf;
+  if (tid == 0) cnt->n_out = nf;
 }
 
 int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -230,8 +263,9 @@ static int extract_level(fl_context *ctx, int modality, const uint8_t *q_img, co
     for (int j = kk >> 1; j > 0; j >>= 1)
       hipLaunchKernelGGL(k_bitonic_step, dim3((np2 + 255) / 256), blk, 0, ctx->stream, keys, np2, kk, j);
   FL_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_select_scattered, dim3(1), dim3(64), 0, ctx->stream, keys, q_img, w, num_features,
-                     modality == 0 ? 0 : (mask ? 2 : 1), w * h, d_cnt, d_feats);
+  // raster / score are dead once the keys exist: reused as the selection's xy / mind2 scratch
+  hipLaunchKernelGGL(k_select_scattered, dim3(1), dim3(SEL_BS), 0, ctx->stream, keys, q_img, w, num_features,
+                     modality == 0 ? 0 : (mask ? 2 : 1), w * h, d_cnt, d_feats, (uint32_t *)raster, (int *)score);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }
