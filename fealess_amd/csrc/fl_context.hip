@@ -4,6 +4,7 @@
 // addPoseInfo (linemod/linemod.cpp:1348-1354, 1617-1642) and the per-frame disk read of the
 // template depth render (CadReco/obj_reco_lmicp.cpp:156-157, uploaded once here instead).
 #include "fl_internal.h"
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 #include <algorithm>
@@ -455,6 +456,7 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   det->n_pts_max = det->max_tw * det->max_th;
   det->off_icp = take(fl_icp_ws_bytes(det->n_pts_max));
   det->ws_stride = fl_align(off, 4096);
+  if (const char *pad = getenv("FL_DEV_WS_PAD")) det->ws_stride += fl_align((size_t)atol(pad), 4096);   // dev aid: stride sensitivity
   det->w0 = w0;
   det->h0 = h0;
   det->max_batch = max_batch;

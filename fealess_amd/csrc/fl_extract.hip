@@ -9,8 +9,8 @@
 //   k_depth_candidates   eroded (5x5) mask, exact chessboard distance to the nearest pixel of another label
 //                        (= cv::distanceTransform(DIST_C, 3) of the per-label images), per-label counts
 //   k_depth_keys         score / label_count -> sort keys
-//   k_bitonic_step       global-memory bitonic sort of the keys: (score desc, raster order asc) is exactly what
-//                        std::stable_sort with Candidate::operator< yields
+//   k_bitonic_step/_local  bitonic sort of the keys (2048-key blocks in LDS, the wider steps in global memory):
+//                        (score desc, raster order asc) is exactly what std::stable_sort with Candidate::operator< yields
 //   k_select_scattered   the greedy selection, sequential in its result but not in its work: every candidate keeps its
 //                        squared distance to the nearest chosen feature, the walk to the next passing candidate is a
 //                        workgroup-wide min (1024 threads)
@@ -148,6 +148,30 @@ __global__ __launch_bounds__(256) void k_bitonic_step(unsigned long long *keys, 
   }
 }
 
+// The bitonic network's steps with partner distance j < SORT_CHUNK stay inside a SORT_CHUNK-key block: one workgroup
+// runs them back to back in LDS instead of one launch per step.  first_kk == 2: every stage up to SORT_CHUNK (a full
+// sort of each block, direction by the global index); otherwise the tail (j = SORT_CHUNK/2 .. 1) of stage kk.
+#define SORT_CHUNK 2048
+__global__ __launch_bounds__(SORT_CHUNK / 2) void k_bitonic_local(unsigned long long *keys, int n_pow2, int first_kk, int last_kk)
+{
+  __shared__ unsigned long long sk[SORT_CHUNK];
+  const int chunk = min(n_pow2, SORT_CHUNK), base = blockIdx.x * chunk, t = threadIdx.x;
+  for (int e = t; e < chunk; e += SORT_CHUNK / 2) sk[e] = keys[base + e];
+  __syncthreads();
+  for (int kk = first_kk; kk <= last_kk; kk <<= 1) {
+    for (int j = min(kk >> 1, chunk >> 1); j > 0; j >>= 1) {
+      if (t < (chunk >> 1)) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const unsigned long long a = sk[i], b = sk[l];
+        const bool up = ((base + i) & kk) == 0;
+        if ((a > b) == up) { sk[i] = b; sk[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = t; e < chunk; e += SORT_CHUNK / 2) keys[base + e] = sk[e];
+}
+
 // selectScatteredFeatures (:135-164).  The reference re-tests every candidate against every chosen feature on every
 // pass (~candidates x features x passes distance tests, with the distance dropping by one per pass).  Here each
 // candidate carries mind2 = its squared distance to the nearest chosen feature so far, so `keep` is one compare,
@@ -259,9 +283,15 @@ static int extract_level(fl_context *ctx, int modality, const uint8_t *q_img, co
   }
   const int np2 = next_pow2(hc.n_cand);
   hipLaunchKernelGGL(k_pad_keys, dim3((np2 + 255) / 256), blk, 0, ctx->stream, keys, d_cnt, np2);
-  for (int kk = 2; kk <= np2; kk <<= 1)
-    for (int j = kk >> 1; j > 0; j >>= 1)
-      hipLaunchKernelGGL(k_bitonic_step, dim3((np2 + 255) / 256), blk, 0, ctx->stream, keys, np2, kk, j);
+  {
+    const int chunk = np2 < SORT_CHUNK ? np2 : SORT_CHUNK, nblk = np2 / chunk;
+    hipLaunchKernelGGL(k_bitonic_local, dim3(nblk), dim3(SORT_CHUNK / 2), 0, ctx->stream, keys, np2, 2, chunk);
+    for (int kk = 2 * SORT_CHUNK; kk <= np2; kk <<= 1) {
+      for (int j = kk >> 1; j >= SORT_CHUNK; j >>= 1)
+        hipLaunchKernelGGL(k_bitonic_step, dim3((np2 + 255) / 256), blk, 0, ctx->stream, keys, np2, kk, j);
+      hipLaunchKernelGGL(k_bitonic_local, dim3(nblk), dim3(SORT_CHUNK / 2), 0, ctx->stream, keys, np2, kk, kk);
+    }
+  }
   FL_HIP(ctx, hipGetLastError());
   // raster / score are dead once the keys exist: reused as the selection's xy / mind2 scratch
   hipLaunchKernelGGL(k_select_scattered, dim3(1), dim3(SEL_BS), 0, ctx->stream, keys, q_img, w, num_features,
