@@ -353,55 +353,67 @@ static int ensure_normal_lut(fl_context *ctx)
   return FL_OK;
 }
 
-// accumBilateral (linemod.cpp:567-579).  The reference accumulates in `long`; with 16-bit depth the
-// sums stay far inside int32 (|A| <= 200, |b| <= 8*5*65535), so 32-bit registers give the same
-// integers; only the final products 617*dd and det*d are widened to 64 bits.
-__device__ __forceinline__ void accum_bilateral(int delta, int i, int j, int *A, int *b, int threshold)
-{
-  const int f = (delta < 0 ? -delta : delta) < threshold ? 1 : 0;     // linemod.cpp:569
-  const int fi = f * i, fj = f * j;
-  A[0] += fi * i;
-  A[1] += fi * j;
-  A[3] += fj * j;
-  b[0] += fi * delta;
-  b[1] += fj * delta;
-}
-
+// accumBilateral (linemod.cpp:567-579) over the 8 ring neighbours, restated on what it adds up to.  With
+// f_k = |delta_k| < threshold and offsets (i, j) in {-5, 0, 5}:  A[0] = sum f*i*i = 25 * #{f_k : i != 0},
+// A[3] likewise for j, A[1] = sum f*i*j = 25 * (f(-,-) + f(+,+) - f(+,-) - f(-,+)), b[0] = sum f*i*delta =
+// 5 * (sum over i = +5 of f*delta  -  sum over i = -5), b[1] likewise for j.  The same integers as the reference's
+// `long` accumulation (|A| <= 150, |b| <= 30 * (threshold - 1)), in 32-bit registers.
+//
 // k_depth_quantize: quantizedNormals (linemod.cpp:595-683) fused with the medianBlur(5) that ends
 // it (:684).  Same execution shape as k_color_quantize: a wavefront owns 64 adjacent columns (60
-// outputs + 2 halo columns per side), walks DQ_CH output rows, keeps the last five rows of normal
-// codes in registers and gets the x-2..x+2 neighbours by wave shuffles.  The codes are 0 or one-hot,
-// i.e. 9 classes ordered like their byte values, so the exact 5x5 median is the class where the
-// cumulative count reaches 13: per-column histograms (nine 5-bit fields in a 64-bit word) are summed
-// over the five columns.  The un-medianed normal image never exists in memory.
+// outputs + 2 halo columns per side), walks DQ_CH output rows and keeps the last five rows in registers.
+// The codes are 0 or one-hot, i.e. 9 classes ordered like their byte values, and the exact 5x5 median is
+// the first class whose CUMULATIVE count reaches 13.  A pixel of class c therefore contributes the
+// pattern "1 in every 4-bit field i >= c" (fields 0..7; class 8's own field would always hold 25 and is
+// implied): five rows add up to a column word (fields <= 5), the x-1, x+1 / x-2, x+2 columns come by
+// whole-wave DPP shifts, 3 + 2 columns are added in 4-bit fields (<= 15, <= 10), and the ">= 13" test runs on
+// the even / odd fields widened to bytes (sum + 115 sets bit 7).  The flags are monotone in the class, so
+// median class = 8 - popcount.  The un-medianed normal image never exists in memory.
 #define DQ_COLS 60
 #define DQ_CH 60
 
-__device__ __forceinline__ unsigned dq_normal_class(const uint16_t *__restrict__ depth, int w, int h, int y, int x,
-                                                    int distance_threshold, int difference_threshold)
+__device__ __forceinline__ unsigned dq_pattern(unsigned cls) { return cls >= 8u ? 0u : 0x11111111u << (4u * cls); }
+
+__device__ __forceinline__ unsigned dq_normal_pattern(const uint16_t *__restrict__ depth, int w, int h, int y, int x,
+                                                      int distance_threshold, int difference_threshold, const uint8_t *lut)
 {
   const int r = 5;
-  if (!(y >= r && y < h - r - 1 && x >= r && x < w - r - 1)) return 0;   // loop bounds :619, :624
+  if (!(y >= r && y < h - r - 1 && x >= r && x < w - r - 1)) return dq_pattern(0);   // loop bounds :619, :624
   const uint16_t *p = depth + (size_t)y * w + x;
   const int d = p[0];
-  if (!(d < distance_threshold)) return 0;
-  int A[4] = {0, 0, 0, 0}, b[2] = {0, 0};
-  accum_bilateral((int)p[-r - r * w] - d, -r, -r, A, b, difference_threshold);
-  accum_bilateral((int)p[0 - r * w] - d, 0, -r, A, b, difference_threshold);
-  accum_bilateral((int)p[+r - r * w] - d, +r, -r, A, b, difference_threshold);
-  accum_bilateral((int)p[-r] - d, -r, 0, A, b, difference_threshold);
-  accum_bilateral((int)p[+r] - d, +r, 0, A, b, difference_threshold);
-  accum_bilateral((int)p[-r + r * w] - d, -r, +r, A, b, difference_threshold);
-  accum_bilateral((int)p[0 + r * w] - d, 0, +r, A, b, difference_threshold);
-  accum_bilateral((int)p[+r + r * w] - d, +r, +r, A, b, difference_threshold);
-  const int det = A[0] * A[3] - A[1] * A[1];
-  const int ddx = A[3] * b[0] - A[1] * b[1];              // |.| <= 2 * 200 * 2.6e6 < 2^31
-  const int ddy = -A[1] * b[0] + A[0] * b[1];
-  float nx = (float)(617LL * ddx);
-  float ny = (float)(617LL * ddy);
-  float nz = (float)(-(long long)det * d);
+  if (!(d < distance_threshold)) return dq_pattern(0);
+  const int t = difference_threshold;
+  const unsigned span = t > 0 ? (unsigned)(2 * t - 1) : 0u;   // t <= 0 admits nothing
+  // neighbours 0..7: (-,-) (0,-) (+,-) (-,0) (+,0) (-,+) (0,+) (+,+)
+  const int e0 = (int)p[-r - r * w] - d, e1 = (int)p[0 - r * w] - d, e2 = (int)p[+r - r * w] - d, e3 = (int)p[-r] - d,
+            e4 = (int)p[+r] - d, e5 = (int)p[-r + r * w] - d, e6 = (int)p[0 + r * w] - d, e7 = (int)p[+r + r * w] - d;
+  // |e| < t  <=>  (unsigned)(e + t - 1) < 2t - 1                                                    :569
+  const bool g0 = (unsigned)(e0 + t - 1) < span, g1 = (unsigned)(e1 + t - 1) < span,
+             g2 = (unsigned)(e2 + t - 1) < span, g3 = (unsigned)(e3 + t - 1) < span,
+             g4 = (unsigned)(e4 + t - 1) < span, g5 = (unsigned)(e5 + t - 1) < span,
+             g6 = (unsigned)(e6 + t - 1) < span, g7 = (unsigned)(e7 + t - 1) < span;
+  const int f0 = g0, f1 = g1, f2 = g2, f3 = g3, f4 = g4, f5 = g5, f6 = g6, f7 = g7;
+  const int m0 = g0 ? e0 : 0, m1 = g1 ? e1 : 0, m2 = g2 ? e2 : 0, m3 = g3 ? e3 : 0, m4 = g4 ? e4 : 0, m5 = g5 ? e5 : 0,
+            m6 = g6 ? e6 : 0, m7 = g7 ? e7 : 0;
+  const int corners = f0 + f2 + f5 + f7;
+  const int A0 = 25 * (corners + f3 + f4), A3 = 25 * (corners + f1 + f6), A1 = 25 * ((f0 + f7) - (f2 + f5));
+  const int b0 = 5 * ((m2 + m4 + m7) - (m0 + m3 + m5)), b1 = 5 * ((m5 + m6 + m7) - (m0 + m1 + m2));
+  const int det = A0 * A3 - A1 * A1;                       // <= 22500
+  float nx, ny, nz;
+  if (t <= 400) {
+    // |b| <= 30 * 399, |dd| <= 250 * |b| < 3.0e6: 617 * dd and det * d (<= 22500 * 65535) fit in int32
+    const int ddx = A3 * b0 - A1 * b1, ddy = -A1 * b0 + A0 * b1;
+    nx = (float)(617 * ddx);
+    ny = (float)(617 * ddy);
+    nz = (float)(-(det * d));
+  } else {
+    const long long ddx = (long long)A3 * b0 - (long long)A1 * b1, ddy = -(long long)A1 * b0 + (long long)A0 * b1;
+    nx = (float)(617LL * ddx);
+    ny = (float)(617LL * ddy);
+    nz = (float)(-(long long)det * d);
+  }
   const float s = sqrtf(nx * nx + ny * ny + nz * nz);
-  if (!(s > 0)) return 0;                                  // shadows of the depth sensor
+  if (!(s > 0)) return dq_pattern(0);                       // shadows of the depth sensor
   const float inv = 1.0f / s;
   nx *= inv;
   ny *= inv;
@@ -410,16 +422,23 @@ __device__ __forceinline__ unsigned dq_normal_class(const uint16_t *__restrict__
   const int v2 = (int)(ny * 10 + 10);
   const int v3 = (int)(nz * 20 + 20);
   // Q7: v3 == 20 is an out-of-bounds read in the reference; defined as 0 here
-  if (!(v1 >= 0 && v1 <= 19 && v2 >= 0 && v2 <= 19 && v3 >= 0 && v3 <= 19)) return 0;
-  const unsigned v = c_normal_lut[v2 * 20 + v1];
-  return v ? (unsigned)(32 - __clz(v)) : 0u;              // 0 -> 0, 1<<k -> k+1 (ascending in value)
+  if (!(v1 >= 0 && v1 <= 19 && v2 >= 0 && v2 <= 19 && v3 >= 0 && v3 <= 19)) return dq_pattern(0);
+  const unsigned v = lut[v2 * 20 + v1];
+  return dq_pattern(v ? (unsigned)(32 - __clz(v)) : 0u);   // 0 -> class 0, 1<<k -> class k+1 (ascending in value)
 }
+
+// whole-wave shift by one lane (gfx9 DPP wave_shl:1 / wave_shr:1); the lane shifted in keeps its own value
+__device__ __forceinline__ unsigned wave_shift_a(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned wave_shift_b(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
 
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t *__restrict__ depth_, size_t in_stride,
                                                         uint8_t *__restrict__ dst_, size_t out_stride, int w, int h,
                                                         int distance_threshold, int difference_threshold, int nstrips,
                                                         int nchunks)
 {
+  __shared__ uint8_t s_lut[400];                           // NORMAL_LUT's 20x20 face: a per-lane lookup every row
+  for (int k = threadIdx.x; k < 400; k += 256) s_lut[k] = c_normal_lut[k];
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave;
   if (item >= nstrips * nchunks) return;
@@ -429,39 +448,25 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t *__restri
   const int x = strip * DQ_COLS + lane - 2;
   const int xc = clampi(x, 0, w - 1);                      // medianBlur replicates the border
   const int y0 = chunk * DQ_CH, y1 = min(h, y0 + DQ_CH);
-  unsigned ring = 0;                                       // five 4-bit class codes, newest in the low nibble
+  unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0;         // cumulative-count patterns of the last five rows, p0 newest
   int center = -1;
-  unsigned cls = 0;
+  unsigned pat = 0;
   for (int yv = y0 - 2; yv <= y1 + 1; ++yv) {
     const int c = clampi(yv, 0, h - 1);
     if (c != center) {                                     // wave-uniform
-      cls = dq_normal_class(depth, w, h, c, xc, distance_threshold, difference_threshold);
+      pat = dq_normal_pattern(depth, w, h, c, xc, distance_threshold, difference_threshold, s_lut);
       center = c;
     }
-    ring = ((ring << 4) | cls) & 0xFFFFFu;
+    p4 = p3; p3 = p2; p2 = p1; p1 = p0; p0 = pat;
     if (yv < y0 + 2) continue;
-    unsigned long long col = 0;                            // column histogram: nine 5-bit counters
-#pragma unroll
-    for (int k = 0; k < 5; ++k) col += 1ull << (5 * ((ring >> (4 * k)) & 15u));
-    unsigned long long sum = col;
-#pragma unroll
-    for (int dlt = 1; dlt <= 2; ++dlt) {
-      const int lo = (int)(col & 0xFFFFFFFFull), hi = (int)(col >> 32);
-      const unsigned long long l = (unsigned)__shfl_up(lo, dlt, 64) | ((unsigned long long)(unsigned)__shfl_up(hi, dlt, 64) << 32);
-      const unsigned long long r = (unsigned)__shfl_down(lo, dlt, 64) | ((unsigned long long)(unsigned)__shfl_down(hi, dlt, 64) << 32);
-      sum += l + r;
-    }
+    const unsigned col = p0 + p1 + p2 + p3 + p4;           // fields <= 5
+    const unsigned a1 = wave_shift_a(col), b1 = wave_shift_b(col), a2 = wave_shift_a(a1), b2 = wave_shift_b(b1);
+    const unsigned s3 = col + a1 + b1, s2 = a2 + b2;       // fields <= 15, <= 10
+    const unsigned te = (s3 & 0x0F0F0F0Fu) + (s2 & 0x0F0F0F0Fu) + 0x73737373u;
+    const unsigned to = ((s3 >> 4) & 0x0F0F0F0Fu) + ((s2 >> 4) & 0x0F0F0F0Fu) + 0x73737373u;
+    const int idx = 8 - __popc((te & 0x80808080u) | ((to & 0x80808080u) >> 1));
     const int yo = yv - 2;
-    if (lane >= 2 && lane < 2 + DQ_COLS && x < w) {
-      int acc = 0, idx = 0;
-      bool done = false;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        acc += (int)((sum >> (5 * i)) & 31);
-        if (!done && acc >= 13) { idx = i; done = true; }
-      }
-      dst[(size_t)yo * w + x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
-    }
+    if (lane >= 2 && lane < 2 + DQ_COLS && x < w) dst[(size_t)yo * w + x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
   }
 }
 

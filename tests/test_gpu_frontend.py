@@ -53,6 +53,18 @@ def test_normals_far_and_thresholds(ctx, oracle):
     assert np.array_equal(ctx.quantized_normals(d2, 900, 20), oracle.quantized_normals(d2, 900, 20))
 
 
+@pytest.mark.parametrize("dist_thr,diff_thr", [(2000, 400), (2000, 401), (65535, 5000), (65535, 65535), (2000, 1), (2000, 0), (2000, -3)])
+def test_normals_difference_threshold_paths(ctx, oracle, dist_thr, diff_thr):
+    """The kernel accumulates in int32 for difference_threshold <= 400 and widens the last products beyond it:
+    both paths, their boundary and the degenerate gates, on smooth and on full-range random depth."""
+    d, _, _ = _scene(3, 320, 240)
+    rough = np.random.default_rng(11).integers(0, 65536, (96, 128)).astype(np.uint16)
+    steps = (500 + 300 * (np.random.default_rng(12).integers(0, 4, (96, 128)))).astype(np.uint16)
+    for depth in (d, rough, steps):
+        got, exp = ctx.quantized_normals(depth, dist_thr, diff_thr), oracle.quantized_normals(depth, dist_thr, diff_thr)
+        assert np.array_equal(got, exp), int((got != exp).sum())
+
+
 @pytest.mark.parametrize("w,h", [(640, 480), (320, 240), (1280, 720), (321, 241), (50, 34)])
 def test_pyrdown_bit_exact(ctx, oracle, w, h):
     bgr = np.random.default_rng(w).integers(0, 256, (h, w, 3), dtype=np.uint8)
