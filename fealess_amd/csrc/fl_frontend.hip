@@ -59,6 +59,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 #define CQ_COLS 60
 #define CQ_CH 60
 
+// Neighbour lanes by whole-wave DPP shifts (gfx9 wave_shr:1 / wave_shl:1): one v_mov_dpp instead of the
+// ds_bpermute + index arithmetic of __shfl_up / __shfl_down; lane 0 / lane 63 keep their own value, as those do.
+__device__ __forceinline__ unsigned wave_from_prev(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned wave_from_next(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }
+
 __device__ __forceinline__ void cq_hrow(const uint8_t *__restrict__ src, int w, int h, int row, int xc, bool interior,
                                         int *h3)
 {
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
     }
     const uint32_t S = (uint32_t)((v0 + (1 << 15)) >> 16) | ((uint32_t)((v1 + (1 << 15)) >> 16) << 8) |
                        ((uint32_t)((v2 + (1 << 15)) >> 16) << 16);
-    const uint32_t L = (uint32_t)__shfl_up((int)S, 1, 64), R = (uint32_t)__shfl_down((int)S, 1, 64);
+    const uint32_t L = wave_from_prev(S), R = wave_from_next(S);
     Sl[0] = Sl[1]; Sl[1] = Sl[2]; Sl[2] = L;
     Sc[0] = Sc[1]; Sc[1] = Sc[2]; Sc[2] = S;
     Sr[0] = Sr[1]; Sr[1] = Sr[2]; Sr[2] = R;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
     // counter word of its own label, the row sum x-1, x, x+1 is formed once and kept for three rows
     const uint32_t q = inside ? (uint32_t)(qi & 7) : 0u;
     const uint32_t oh = 1u << (4 * q);
-    const uint32_t ohl = (uint32_t)__shfl_up((int)oh, 1, 64), ohr = (uint32_t)__shfl_down((int)oh, 1, 64);
+    const uint32_t ohl = wave_from_prev(oh), ohr = wave_from_next(oh);
     Qp[0] = Qp[1]; Qp[1] = Qp[2]; Qp[2] = oh + ohl + ohr;
     Mg[0] = Mg[1]; Mg[1] = Mg[2]; Mg[2] = (float)bmag;
     if (yv < y0 + 2) continue;
@@ -427,10 +432,6 @@ __device__ __forceinline__ unsigned dq_normal_pattern(const uint16_t *__restrict
   return dq_pattern(v ? (unsigned)(32 - __clz(v)) : 0u);   // 0 -> class 0, 1<<k -> class k+1 (ascending in value)
 }
 
-// whole-wave shift by one lane (gfx9 DPP wave_shl:1 / wave_shr:1); the lane shifted in keeps its own value
-__device__ __forceinline__ unsigned wave_shift_a(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xF, 0xF, false); }
-__device__ __forceinline__ unsigned wave_shift_b(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false); }
-
 __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t *__restrict__ depth_, size_t in_stride,
                                                         uint8_t *__restrict__ dst_, size_t out_stride, int w, int h,
                                                         int distance_threshold, int difference_threshold, int nstrips,
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t *__restri
     p4 = p3; p3 = p2; p2 = p1; p1 = p0; p0 = pat;
     if (yv < y0 + 2) continue;
     const unsigned col = p0 + p1 + p2 + p3 + p4;           // fields <= 5
-    const unsigned a1 = wave_shift_a(col), b1 = wave_shift_b(col), a2 = wave_shift_a(a1), b2 = wave_shift_b(b1);
+    const unsigned a1 = wave_from_next(col), b1 = wave_from_prev(col), a2 = wave_from_next(a1), b2 = wave_from_prev(b1);
     const unsigned s3 = col + a1 + b1, s2 = a2 + b2;       // fields <= 15, <= 10
     const unsigned te = (s3 & 0x0F0F0F0Fu) + (s2 & 0x0F0F0F0Fu) + 0x73737373u;
     const unsigned to = ((s3 >> 4) & 0x0F0F0F0Fu) + ((s2 >> 4) & 0x0F0F0F0Fu) + 0x73737373u;

@@ -586,8 +586,13 @@ __device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *
   if (last < 0) { NN_UNPACK(best, bi, bd) return; }
   // The search is latency-bound and a wave pays for its slowest lane, so round trips are what counts:
   // the headers of 4 grid rows (8 loads) are fetched together, then the candidates of all 4 row segments
-  // are enumerated as ONE flat list, 16 per round trip -- a lane needs ceil(total / 16) rounds however the
-  // candidates are spread over the rows.  Out-of-range slots are masked, their (clamped) loads harmless.
+  // are enumerated as ONE flat list, FL_ICP_NB per round trip -- a lane needs ceil(total / NB) rounds however the
+  // candidates are spread over the rows.  Slots past the end of the list are NOT masked: they read points that
+  // follow the last row segment (clamped to the cloud), and looking at extra reference points never changes the
+  // answer -- the minimum over a superset that still contains every point within the search radius is the same
+  // nearest neighbour, ties to the lowest index included.  (Chunked per-row reads with no index mapping at all
+  // were measured too: fewer instructions per candidate, but a wave then pays for its longest ROW, not its
+  // longest list: 20.3 ms vs 17.6 ms.)
   for (int cy = cy0; cy <= cy1; cy += 4) {
     int rb[4], re[4];
 #pragma unroll
@@ -614,7 +619,7 @@ __device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *
         p[v] = ld_u32(sref, min(k + adj, last));
       }
 #pragma unroll
-      for (int v = 0; v < FL_ICP_NB; ++v) NN_CONSIDER_IF(p[v], base + v < tot)
+      for (int v = 0; v < FL_ICP_NB; ++v) NN_CONSIDER(p[v])
     }
   }
   NN_UNPACK(best, bi, bd)
@@ -872,14 +877,17 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           const int g = max(j2, 0);
           const F3 r2v = ld3_u32(ref, g);
           const float r2[3] = {r2v.x, r2v.y, r2v.z};
-          const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f
+          const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f: (+0) * (+0)
           float (*tile)[ICP_TS] = S.prod[t & 1];
+          float mm[3], rr[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { mm[q] = have ? m1[q] : 0.0f; rr[q] = have ? r1[q] : 0.0f; }
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = have ? m1[a] * r1[b] : 0.0f;   // (*it_s) * (*it_ref).t()
+            for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = mm[a] * rr[b];   // (*it_s) * (*it_ref).t()
 #pragma unroll
-          for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = have ? m1[q] : 0.0f; tile[12 + q][slot] = have ? r1[q] : 0.0f; }
+          for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = mm[q]; tile[12 + q][slot] = rr[q]; }
           j1 = j2;
 #pragma unroll
           for (int q = 0; q < 3; ++q) { m1[q] = m2[q]; r1[q] = r2[q]; m2[q] = m3[q]; }
