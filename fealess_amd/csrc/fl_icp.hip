@@ -400,6 +400,11 @@ __device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
   return v;
 }
 
+// An UPPER bound of sqrt(x) for the search-radius bookkeeping (bnd[]): the hardware's 1-ulp v_sqrt_f32 inflated past
+// its error (and past a flushed denormal) instead of the ~15-instruction correctly rounded sqrtf.  Any over-estimate
+// only widens the visited area; the nearest neighbour found is the same.
+__device__ __forceinline__ float sqrt_upper(float x) { return __builtin_amdgcn_sqrtf(x) * 1.000001f + 1.1e-19f; }
+
 // ---- uniform x/y grid over the reference cloud --------------------------------------------------
 __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
 {
@@ -672,7 +677,7 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
             o[1] += Topt[1];
             o[2] += Topt[2];
             const float mx = o[0] - a[0], my = o[1] - a[1], mz = o[2] - a[2];
-            move = sqrtf(mx * mx + my * my + mz * mz);
+            move = sqrt_upper(mx * mx + my * my + mz * mz);
             a[0] = o[0];
             a[1] = o[1];
             a[2] = o[2];
@@ -684,7 +689,7 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
         } else {
           // first bound: the index pair (n_ref >= n_model); NaN/inf simply disable the bound
           const float ex = a[0] - b0, ey = a[1] - b1, ez = a[2] - b2;
-          bnd[i] = sqrtf(ex * ex + ey * ey + ez * ez);
+          bnd[i] = sqrt_upper(ex * ex + ey * ey + ez * ez);
         }
         if (vvalid(b2) && vvalid(a[2])) {
           const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
@@ -816,7 +821,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
         const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
         if (keep) ++kept;
         nn[i] = keep ? j : -1;
-        if (j >= 0) bnd[i] = sqrtf(d);                    // else: the old partner is still within qb
+        if (j >= 0) bnd[i] = sqrt_upper(d);               // else: the old partner is still within qb
         if (plane && keep) {
           // linearised point-to-plane: residual e = n.(m - r), Jacobian row J = [m x n, n] wrt (omega, t);
           // ds = upper triangle of sum J J^T (21) followed by sum J e (6)
