@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-frontend", action="store_true",
+                    help="quantise and spread the finer pyramid levels in full before the scan (the reference's order) instead of "
+                         "only in the tiles the scan's candidates touch; same results")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true",
@@ -163,6 +166,8 @@ def main():
     bank, bgrs, depths, scenes = build_workload(ctx, args, rank)
     det = api.Detector(ctx, 2, T)
     det.add_class(bank)
+    if args.eager_frontend:
+        os.environ["FL_EAGER_FRONTEND"] = "1"      # read by fl_detector_finalize
     det.finalize(640, 480, max_batch=args.batch, max_candidates=4096)
     B = args.batch
     d_bgr = torch.from_numpy(bgrs).cuda()
@@ -251,7 +256,9 @@ def main():
                                    f"levels T={T}, {args.icp_iters} ICP iterations forced (dist_mean_thr=-1, "
                                    f"dist_diff_thr=-3e38), ICP mode {args.icp_mode}",
                        "frames_per_step_per_gpu": B, "templates": bank.n_pyramids, "levels": args.levels,
-                       "parallelism": f"frame-sharded x{world}"},
+                       "parallelism": f"frame-sharded x{world}",
+                       "fine_levels": "eager (whole images, before the scan)" if args.eager_frontend else
+                                      "lazy (tiles the scan's candidates touch; --eager-frontend for whole images)"},
             "ms_per_icp_iter": round(times["icp_ms"] / max(1, args.icp_iters), 5),
             "ms_per_icp_iter_per_frame_amortised": round(times["icp_ms"] / max(1, iters), 7),
             "detections": f"{found}/{B}", "icp_iters_mean": round(iters / max(1, found), 2),

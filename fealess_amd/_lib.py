@@ -58,7 +58,8 @@ class RecognitionParams(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [("frontend_ms", C.c_float), ("linmem_ms", C.c_float), ("scan_ms", C.c_float), ("refine_ms", C.c_float),
                 ("sort_ms", C.c_float), ("backproject_ms", C.c_float), ("icp_ms", C.c_float), ("total_ms", C.c_float),
-                ("icp_iters_total", C.c_int32), ("icp_launches", C.c_int32), ("scan_algorithmic_bytes", C.c_double)]
+                ("icp_iters_total", C.c_int32), ("icp_launches", C.c_int32), ("scan_algorithmic_bytes", C.c_double),
+                ("lazy_frontend_ms", C.c_float), ("reserved0", C.c_float)]
 
 
 _P = C.c_void_p

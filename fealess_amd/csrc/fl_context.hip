@@ -450,6 +450,14 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   }
   det->off_tmp = take((size_t)w0 * h0);
   det->off_count = take(256);
+  det->off_tiles = take((size_t)(L > 1 ? L - 1 : 1) * 2 * FL_TILE_WORDS * sizeof(uint32_t));
+  det->lazy_capable = L > 1;
+  for (int l = 0; l + 1 < L; ++l) {
+    const FlLevelGeom &g = det->geom[l];
+    if (((g.w + FL_TILE - 1) / FL_TILE) * ((g.h + FL_TILE - 1) / FL_TILE) > FL_TILE_WORDS * 32) det->lazy_capable = false;
+  }
+  { const char *e = getenv("FL_EAGER_FRONTEND"); det->eager_env = e && *e && *e != '0'; }
+  { const char *e = getenv("FL_DEV_POISON"); det->poison_env = e && *e && *e != '0'; }
   det->off_cand = take((size_t)cap * sizeof(FlCand));
   det->off_keys = take((size_t)cap * 16);
   det->off_match = take((size_t)cap * sizeof(fl_match));

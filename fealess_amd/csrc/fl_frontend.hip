@@ -101,12 +101,17 @@ __device__ __forceinline__ void cq_hrow(const uint8_t *__restrict__ src, int w, 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, FL_CQ_WPE))) void k_color_quantize(const uint8_t *__restrict__ bgr, size_t in_stride,
                                                         uint8_t *__restrict__ dst, size_t out_stride, int w, int h,
                                                         float threshold_sq, int nstrips, int nchunks,
-                                                        float *__restrict__ mag_out)
+                                                        float *__restrict__ mag_out, const uint32_t *__restrict__ tiles,
+                                                        size_t tiles_stride)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + wave;
   if (item >= nstrips * nchunks) return;
   const int strip = item % nstrips, chunk = item / nstrips;
+  if (tiles) {             // lazy fine level: only the tiles whose pixels some candidate's spread bytes read
+    const int t = chunk * nstrips + strip;
+    if (!((tiles[(size_t)blockIdx.z * tiles_stride + (t >> 5)] >> (t & 31)) & 1u)) return;   // wave-uniform
+  }
   const uint8_t *src = bgr + (size_t)blockIdx.z * in_stride;
   uint8_t *out = dst + (size_t)blockIdx.z * out_stride;
   const int x = strip * CQ_COLS + lane - 2;
@@ -208,15 +213,22 @@ int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t
   return fl_launch_quantized_orientations_mag(ctx, bgr, in_stride, dst, out_stride, n_frames, w, h, weak_threshold, nullptr);
 }
 
-int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst,
-                                         size_t out_stride, int n_frames, int w, int h, float weak_threshold, float *mag_out)
+static_assert(CQ_COLS == FL_TILE && CQ_CH == FL_TILE, "the lazy tile grid is k_color_quantize's work decomposition");
+static int launch_color_quantize(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst, size_t out_stride, int n_frames,
+                                 int w, int h, float weak_threshold, float *mag_out, const uint32_t *tiles, size_t tiles_stride)
 {
   const int nstrips = (w + CQ_COLS - 1) / CQ_COLS, nchunks = (h + CQ_CH - 1) / CQ_CH;
   dim3 grid((nstrips * nchunks + 3) / 4, 1, n_frames);
   hipLaunchKernelGGL(k_color_quantize, grid, dim3(256), 0, ctx->stream, bgr, in_stride, dst, out_stride, w, h,
-                     weak_threshold * weak_threshold, nstrips, nchunks, mag_out);
+                     weak_threshold * weak_threshold, nstrips, nchunks, mag_out, tiles, tiles_stride);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
+}
+
+int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst,
+                                         size_t out_stride, int n_frames, int w, int h, float weak_threshold, float *mag_out)
+{
+  return launch_color_quantize(ctx, bgr, in_stride, dst, out_stride, n_frames, w, h, weak_threshold, mag_out, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -538,10 +550,16 @@ int fl_launch_resize_nn_half(fl_context *ctx, const uint8_t *src, size_t in_stri
 // Modality::process + pyrDown + quantize for every level (linemod.cpp:1369-1416) of n_frames frames
 // resident in the detector workspace.  Default modality parameters (linemod.cpp:515-519, 827-832).
 int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_t bgr_stride, const uint16_t *depth,
-                       size_t depth_stride)
+                       size_t depth_stride, bool allow_lazy)
 {
   fl_context *ctx = det->ctx;
   int rc;
+  // Lazy fine levels: everything that feeds the coarsest level (colour pyramid, depth quantisation and its NN
+  // pyramid, the coarsest colour quantisation) runs here; the colour quantisation of the finer levels waits for the
+  // scan's candidates (fl_launch_lazy_level).
+  det->lazy = allow_lazy && det->lazy_capable && !det->eager_env;
+  det->lazy_bgr = bgr;
+  det->lazy_bgr_stride = bgr_stride;
   for (int l = 0; l < det->L; ++l) {
     const FlLevelGeom &g = det->geom[l];
     if (l > 0) {
@@ -560,11 +578,37 @@ int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_
                                        det->ws_stride, n_frames, g.w, g.h, 2000, 50);
       if (rc) return rc;
     }
+    if (det->lazy && l < det->L - 1) continue;
     rc = fl_launch_quantized_orientations(ctx, l == 0 ? bgr : det->d_ws + g.bgr_off, l == 0 ? bgr_stride : det->ws_stride,
                                           det->d_ws + g.quant_off[0], det->ws_stride, n_frames, g.w, g.h, 10.0f);
     if (rc) return rc;
   }
   if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[1], ctx->stream));
+  return FL_OK;
+}
+
+// Fine level `level` of a lazy batch, after k_mark_tiles: colour quantisation of the tiles in the "quantised pixels
+// needed" bitmap, then both modalities' spread images in the rows/columns of the "spread bytes needed" bitmap.
+int fl_launch_lazy_level(fl_detector *det, int n_frames, int level)
+{
+  fl_context *ctx = det->ctx;
+  const FlLevelGeom &g = det->geom[level];
+  const uint32_t *tiles = (const uint32_t *)(det->d_ws + det->off_tiles) + (size_t)level * 2 * FL_TILE_WORDS;
+  const size_t tstride = det->ws_stride / sizeof(uint32_t);
+  if (det->poison_env) {   // dev aid: a byte read outside the marked tiles must not look plausible
+    FL_HIP(ctx, hipMemset2DAsync(det->d_ws + g.quant_off[0], det->ws_stride, 0xFF, (size_t)g.w * g.h, n_frames, ctx->stream));
+    for (int m = 0; m < det->M; ++m)
+      FL_HIP(ctx, hipMemset2DAsync(det->d_ws + g.spread_off[m], det->ws_stride, 0xFF, (size_t)g.w * g.h, n_frames, ctx->stream));
+  }
+  int rc = launch_color_quantize(ctx, level == 0 ? det->lazy_bgr : det->d_ws + g.bgr_off, level == 0 ? det->lazy_bgr_stride : det->ws_stride,
+                                 det->d_ws + g.quant_off[0], det->ws_stride, n_frames, g.w, g.h, 10.0f, nullptr,
+                                 tiles + FL_TILE_WORDS, tstride);
+  if (rc) return rc;
+  for (int m = 0; m < det->M; ++m) {
+    rc = fl_launch_spread_tiles(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.spread_off[m], det->ws_stride, n_frames,
+                                g.w, g.h, g.T, tiles, tstride);
+    if (rc) return rc;
+  }
   return FL_OK;
 }
 

@@ -69,6 +69,10 @@ struct FlCand {          // a candidate / match in flight
   float sim;
 };
 
+#define FL_TILE 60                 // tile edge in pixels (= CQ_COLS = CQ_CH of k_color_quantize)
+#define FL_TILE_WORDS 64           // bitmap words per frame, level and kind: up to 2048 tiles
+#define FL_NUM_EVENTS 24
+
 struct FlLevelGeom {
   int32_t w, h, T, W, H, WH;
   uint32_t stride;       // bytes per label block
@@ -119,6 +123,16 @@ struct fl_detector {
   size_t ws_stride = 0;
   size_t off_bgr = 0, off_depth = 0, off_cand = 0, off_count = 0, off_keys = 0, off_match = 0;
   size_t off_icp = 0, off_tmp = 0;
+  // Lazy fine levels (fl_recognize_*): the finer levels are only ever read by k_refine, around the candidates the
+  // coarse scan produced.  Their colour quantisation and spread images are therefore computed after the scan and
+  // only in the 60x60-pixel tiles the candidates' 16x16 patches can touch (k_mark_tiles).  Two bitmaps per frame
+  // and fine level: tiles whose spread bytes are read, tiles whose quantised pixels those spreads read.
+  size_t off_tiles = 0;                  // [L-1][2][FL_TILE_WORDS] uint32 per frame
+  bool lazy_capable = false;             // tile grid fits the bitmaps
+  bool lazy = false;                     // this batch runs lazily (set by fl_launch_frontend)
+  bool eager_env = false, poison_env = false;   // FL_EAGER_FRONTEND / FL_DEV_POISON (dev knobs, read at finalize)
+  const uint8_t *lazy_bgr = nullptr;     // level-0 colour frames of the batch in flight
+  size_t lazy_bgr_stride = 0;
   int n_pts_max = 0;
   int last_batch = 0;
   bool last_from_images = false;
@@ -127,7 +141,7 @@ struct fl_detector {
   fl_recognition_result *d_results = nullptr;   // max_batch
   fl_recognition_result *h_results = nullptr;   // pinned
   // timing
-  hipEvent_t ev[10] = {nullptr};
+  hipEvent_t ev[FL_NUM_EVENTS] = {nullptr};   // 0..6 stage boundaries, 8 + 2l / 9 + 2l around the lazy work of fine level l
   fl_stage_times times;
   bool have_times = false;
   double scan_bytes_per_frame = 0;       // SURVEY 8(d) B_tmpl summed over the bank
@@ -142,6 +156,7 @@ int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_strid
 int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread,
                      size_t spread_stride, int n_frames, int w, int h, int T);
 int fl_launch_match_core(fl_detector *det, int n_frames, float threshold);
+int fl_launch_lazy_level(fl_detector *det, int n_frames, int level);   // frontend: colour quantisation + spreads of the marked tiles
 // frontend
 int fl_launch_quantized_orientations(fl_context *ctx, const uint8_t *bgr, size_t in_stride,
                                      uint8_t *dst, size_t out_stride, int n_frames, int w, int h,
@@ -157,7 +172,9 @@ int fl_launch_resize_nn_half(fl_context *ctx, const uint8_t *src, size_t in_stri
 int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, size_t in_stride, uint8_t *dst, size_t out_stride,
                                          int n_frames, int w, int h, float weak_threshold, float *mag_out);
 int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_t bgr_stride,
-                       const uint16_t *depth, size_t depth_stride);
+                       const uint16_t *depth, size_t depth_stride, bool allow_lazy);
+int fl_launch_spread_tiles(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread, size_t spread_stride,
+                           int n_frames, int w, int h, int T, const uint32_t *tiles, size_t tiles_stride);
 // icp
 size_t fl_icp_ws_bytes(int n_pts_max);
 int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, const fl_recognition_params *p, const uint16_t *depth,

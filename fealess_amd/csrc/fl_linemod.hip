@@ -14,6 +14,7 @@
 // All integer work; the only float expressions are the reference's own score formulas, built
 // with -ffp-contract=off so each operator is one IEEE binary32 operation.
 #include "fl_internal.h"
+#include <limits.h>
 
 // ------------------------------------------------------------------------------------------
 // k_build_lm: one thread per (grid cell, linear position p); the 8 label bytes it produces go
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256) void k_build_lm(const uint8_t *__restrict__ qu
 // separable OR as k_build_lm.  Those levels are only read by k_refine (a few 16x16 patches per
 // frame), which evaluates the response LUT on the fly instead of reading 8 linear memories.
 __global__ __launch_bounds__(256) void k_spread(const uint8_t *__restrict__ quant, size_t quant_stride,
-                                                uint8_t *__restrict__ spread, size_t spread_stride, int w, int h, int T, int RS)
+                                                uint8_t *__restrict__ spread, size_t spread_stride, int w, int h, int T, int RS,
+                                                const uint32_t *__restrict__ tiles, size_t tiles_stride)
 {
   extern __shared__ __align__(16) uint8_t smem[];
   const int ws = w + 16, rows_in = RS + T - 1;
@@ -145,17 +147,35 @@ __global__ __launch_bounds__(256) void k_spread(const uint8_t *__restrict__ quan
   uint8_t *out = spread + (size_t)blockIdx.z * spread_stride;
   const int y0 = blockIdx.x * RS, tid = threadIdx.x;
   const int ws4 = ws >> 2, w4 = w >> 2;
-  const float inv_ws4 = 1.0f / (float)ws4, inv_w4 = 1.0f / (float)w4;
-  for (int i = tid; i < rows_in * ws4; i += 256) {
-    const int r = div_small(i, inv_ws4), c4 = i - r * ws4;
+  // column window [lo4, lo4 + n_out) in dwords: everything, or (lazy fine level) the span of the marked tiles
+  // that these rows cross -- nothing marked, nothing to do
+  int lo4 = 0, n_out = w4;
+  if (tiles) {
+    const uint32_t *tf = tiles + (size_t)blockIdx.z * tiles_stride;
+    const int nstrips = (w + FL_TILE - 1) / FL_TILE;
+    const int c0 = y0 / FL_TILE, c1 = min(y0 + RS - 1, h - 1) / FL_TILE;
+    int smin = nstrips, smax = -1;
+    for (int c = c0; c <= c1; ++c)
+      for (int st = 0; st < nstrips; ++st) {
+        const int t = c * nstrips + st;
+        if ((tf[t >> 5] >> (t & 31)) & 1u) { smin = min(smin, st); smax = max(smax, st); }
+      }
+    if (smax < 0) return;                                  // workgroup-uniform
+    lo4 = (smin * FL_TILE) >> 2;
+    n_out = (min(w, (smax + 1) * FL_TILE) + 3) / 4 - lo4;
+  }
+  const int n_in = min(ws4, lo4 + n_out + 3) - lo4;        // the horizontal OR of dword c reads dwords c .. c + 3
+  const float inv_in = 1.0f / (float)n_in, inv_out = 1.0f / (float)n_out;
+  for (int i = tid; i < rows_in * n_in; i += 256) {
+    const int r = div_small(i, inv_in), c4 = lo4 + (i - r * n_in);
     const int y = y0 + r;
     uint32_t v = 0;
     if (y < h && c4 < w4) v = *(const uint32_t *)(q + (size_t)y * w + 4 * c4);
-    ((uint32_t *)A)[i] = v;
+    ((uint32_t *)A)[r * ws4 + c4] = v;
   }
   __syncthreads();
-  for (int i = tid; i < rows_in * w4; i += 256) {
-    const int r = div_small(i, inv_w4), c4 = i - r * w4;
+  for (int i = tid; i < rows_in * n_out; i += 256) {
+    const int r = div_small(i, inv_out), c4 = lo4 + (i - r * n_out);
     const uint32_t *src = (const uint32_t *)(A + (size_t)r * ws) + c4;
     const unsigned long long lo = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
     const unsigned long long hi = (unsigned long long)src[2] | ((unsigned long long)src[3] << 32);
@@ -164,8 +184,8 @@ __global__ __launch_bounds__(256) void k_spread(const uint8_t *__restrict__ quan
     ((uint32_t *)(B + (size_t)r * ws))[c4] = (uint32_t)acc;
   }
   __syncthreads();
-  for (int i = tid; i < RS * w4; i += 256) {
-    const int r = div_small(i, inv_w4), c4 = i - r * w4;
+  for (int i = tid; i < RS * n_out; i += 256) {
+    const int r = div_small(i, inv_out), c4 = lo4 + (i - r * n_out);
     if (y0 + r >= h) continue;
     uint32_t acc = 0;
     for (int rr = 0; rr < T; ++rr) acc |= ((const uint32_t *)(B + (size_t)(r + rr) * ws))[c4];
@@ -186,8 +206,10 @@ __global__ __launch_bounds__(256) void k_spread_generic(const uint8_t *__restric
   spread[(size_t)blockIdx.z * spread_stride + (size_t)y * w + x] = (uint8_t)b;
 }
 
-int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread, size_t spread_stride,
-                     int n_frames, int w, int h, int T)
+// tiles == nullptr: the whole image.  Otherwise (lazy fine level) only what the marked tiles need; the generic
+// fallback kernel ignores the marks and spreads everything, which is always sufficient.
+int fl_launch_spread_tiles(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread, size_t spread_stride,
+                           int n_frames, int w, int h, int T, const uint32_t *tiles, size_t tiles_stride)
 {
   const bool aligned = ((uintptr_t)quant % 4 == 0) && (quant_stride % 4 == 0) && ((uintptr_t)spread % 4 == 0) && (spread_stride % 4 == 0);
   if (w % 4 == 0 && T <= 8 && T >= 2 && aligned) {
@@ -201,7 +223,8 @@ int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride,
     if (lds <= 64 * 1024) {
       const int RS = k * T;
       dim3 grid((h + RS - 1) / RS, 1, n_frames);
-      hipLaunchKernelGGL(k_spread, grid, dim3(256), lds, ctx->stream, quant, quant_stride, spread, spread_stride, w, h, T, RS);
+      hipLaunchKernelGGL(k_spread, grid, dim3(256), lds, ctx->stream, quant, quant_stride, spread, spread_stride, w, h, T, RS,
+                         tiles, tiles_stride);
       FL_HIP(ctx, hipGetLastError());
       return FL_OK;
     }
@@ -210,6 +233,12 @@ int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride,
   hipLaunchKernelGGL(k_spread_generic, grid, dim3(256), 0, ctx->stream, quant, quant_stride, spread, spread_stride, w, h, T);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
+}
+
+int fl_launch_spread(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread, size_t spread_stride,
+                     int n_frames, int w, int h, int T)
+{
+  return fl_launch_spread_tiles(ctx, quant, quant_stride, spread, spread_stride, n_frames, w, h, T, nullptr, 0);
 }
 
 int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *lm,
@@ -538,6 +567,88 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
   }
 }
 
+// k_mark_tiles (lazy fine levels): which 60x60 tiles of level a.level will k_refine read?  One workgroup per
+// frame, one wave per candidate, lane = feature, with k_refine's own arithmetic: a feature whose 16x16 patch stays
+// inside its linear memory reads the spread bytes (fy + r*T, fx + c*T), r, c < 16; the candidate's features span a
+// rectangle, its tiles go into bitmap 0 ("spread bytes read") and the tiles of the rectangle grown by T-1 to the
+// right and below into bitmap 1 ("quantised pixels those spreads are made of").  Anything unusual -- a feature
+// outside the image, a patch that leaves its linear memory and wraps (Q1/Q2) -- marks the whole frame, which is
+// the eager computation.
+__global__ __launch_bounds__(256) void k_mark_tiles(RefineArgs a, size_t off_tiles)
+{
+  __shared__ uint32_t bm[2][FL_TILE_WORDS];
+  __shared__ int s_all;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int frame = blockIdx.x;
+  uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
+  for (int i = threadIdx.x; i < 2 * FL_TILE_WORDS; i += 256) bm[0][i] = 0;
+  if (threadIdx.x == 0) s_all = 0;
+  __syncthreads();
+  const int n = min(*(const int *)(ws + a.off_count), a.cap);
+  const FlCand *cand = (const FlCand *)(ws + a.off_cand);
+  const int T = a.T, W = a.W, H = a.H;
+  const int border = 8 * T;
+  const int nstrips = (a.w + FL_TILE - 1) / FL_TILE, nchunks = (a.h + FL_TILE - 1) / FL_TILE;
+  for (int ci = wave; ci < n; ci += 4) {
+    const FlCand cd = cand[ci];
+    const int g = __builtin_amdgcn_readfirstlane(cd.g);
+    if (g < 0) continue;
+    const FlFineHdr *hdr = a.hdr + ((size_t)g * a.Lm1 + a.level) * a.M;
+    const int max_x = a.w - hdr[0].width - border, max_y = a.h - hdr[0].height - border;
+    int x = __builtin_amdgcn_readfirstlane(cd.x) * 2 + 1, y = __builtin_amdgcn_readfirstlane(cd.y) * 2 + 1;
+    x = max(x, border);
+    y = max(y, border);
+    x = min(x, max_x);
+    y = min(y, max_y);
+    const int offset_x = (x / T - 8) * T, offset_y = (y / T - 8) * T;
+    const int offx_t = offset_x / T, offy_t = offset_y / T;
+    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+    bool odd = false;
+    for (int m = 0; m < a.M; ++m) {
+      const FlFineHdr h = hdr[m];
+      if (lane < h.feat_count) {
+        const FlFineFeat f = a.feat[h.feat_begin + lane];
+        const int fx = (int)f.x + offset_x, fy = (int)f.y + offset_y;
+        const bool in = fx >= 0 && fy >= 0 && fx < a.w && fy < a.h;
+        const int lm_x = (int)f.qx + offx_t, lm_y = (int)f.qy + offy_t;
+        if (in && lm_x + 15 < W && lm_y + 15 < H) {
+          x0 = min(x0, fx); y0 = min(y0, fy);
+          x1 = max(x1, fx + 15 * T); y1 = max(y1, fy + 15 * T);
+        } else {
+          odd = true;
+        }
+      }
+      if (h.feat_count > 64) odd = true;                    // k_refine keeps one feature per lane
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      x0 = min(x0, __shfl_xor(x0, sft, 64)); y0 = min(y0, __shfl_xor(y0, sft, 64));
+      x1 = max(x1, __shfl_xor(x1, sft, 64)); y1 = max(y1, __shfl_xor(y1, sft, 64));
+    }
+    if (__any(odd) || x1 >= a.w || y1 >= a.h) { if (lane == 0) s_all = 1; continue; }
+    if (x1 < 0) continue;                                  // no feature at all
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      const int grow = kind ? T - 1 : 0;
+      const int s0 = x0 / FL_TILE, s1 = min(a.w - 1, x1 + grow) / FL_TILE, c0 = y0 / FL_TILE, c1 = min(a.h - 1, y1 + grow) / FL_TILE;
+      const int ns = s1 - s0 + 1, nt = ns * (c1 - c0 + 1);
+      for (int t = lane; t < nt; t += 64) {
+        const int c = t / ns, tile = (c0 + c) * nstrips + s0 + (t - c * ns);
+        atomicOr(&bm[kind][tile >> 5], 1u << (tile & 31));
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t *out = (uint32_t *)(ws + off_tiles) + (size_t)a.level * 2 * FL_TILE_WORDS;
+  const int ntiles = nstrips * nchunks;
+  for (int i = threadIdx.x; i < 2 * FL_TILE_WORDS; i += 256) {
+    const int wd = i % FL_TILE_WORDS;
+    uint32_t v = bm[0][i];
+    if (s_all) v = wd * 32 + 32 <= ntiles ? 0xFFFFFFFFu : (wd * 32 < ntiles ? (1u << (ntiles - wd * 32)) - 1u : 0u);
+    out[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_sort_unique: one 1024-thread workgroup per frame.  128-bit keys, sorted descending:
 //   hi = similarity bits << 32 | (0x7FFFFFFF - template_id)     (Match::operator<, linemod.hpp:262)
@@ -698,6 +809,7 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
   for (int l = L - 2; l >= 0; --l) {
     const FlLevelGeom &g = det->geom[l];
     RefineArgs a;
+    const bool lazy_level = det->lazy;
     a.hdr = det->d_fine_hdr;
     a.feat = det->d_fine_feat;
     a.ws = det->d_ws;
@@ -715,6 +827,15 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.H = g.H;
     a.cap = det->cap;
     a.threshold = threshold;
+    if (lazy_level) {
+      // the level's colour quantisation and spread images, only where these candidates will look
+      if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[8 + 2 * l], ctx->stream));
+      hipLaunchKernelGGL(k_mark_tiles, dim3(n_frames), dim3(256), 0, ctx->stream, a, det->off_tiles);
+      FL_HIP(ctx, hipGetLastError());
+      int rc = fl_launch_lazy_level(det, n_frames, l);
+      if (rc) return rc;
+      if (det->have_times) FL_HIP(ctx, hipEventRecord(det->ev[9 + 2 * l], ctx->stream));
+    }
     // few workgroups per frame: candidates are typically tens per frame and idle workgroups are not
     // free (every wave still fetches the frame's counter); heavy frames just loop longer
     dim3 grid(n_frames >= 64 ? 4 : (n_frames >= 8 ? 32 : 256), n_frames);
@@ -748,6 +869,7 @@ int fl_launch_match_core(fl_detector *det, int n_frames, float threshold)
   for (int l = 0; l < det->L; ++l) {
     const FlLevelGeom &g = det->geom[l];
     for (int m = 0; m < det->M; ++m) {
+      if (det->lazy && l < det->L - 1) continue;           // spread of a fine level: after the scan, marked tiles only
       int rc = l == det->L - 1
                    ? fl_launch_build_lm(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.lm_off[m],
                                         det->ws_stride, n_frames, g.w, g.h, g.T)
@@ -791,6 +913,7 @@ extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quanti
                                  mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     }
   det->have_times = false;
+  det->lazy = false;                     // every level's quantised image was just supplied
   int rc = fl_launch_match_core(det, 1, threshold);
   if (rc) return rc;
   det->last_batch = 1;
@@ -830,8 +953,9 @@ extern "C" int fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const
   FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_bgr, bgr, px * 3, kind, ctx->stream));
   if (det->M == 2) FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_depth, depth, px * 2, kind, ctx->stream));
   det->have_times = false;
+  // whole quantised pyramids (masks apply to them, fl_last_quantized returns them): no lazy levels here
   int rc = fl_launch_frontend(det, 1, det->d_ws + det->off_bgr, det->ws_stride,
-                              (const uint16_t *)(det->d_ws + det->off_depth), det->ws_stride);
+                              (const uint16_t *)(det->d_ws + det->off_depth), det->ws_stride, false);
   if (rc) return rc;
   uint8_t *d_mask = nullptr;
   if (masks) {
@@ -912,6 +1036,9 @@ extern "C" int fl_last_quantized(fl_detector *det, uint8_t *out)
   if (!det || !out) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
   if (!det->finalized || det->last_batch < 1) return fl_set_error(ctx, FL_ERR_STATE, "no frame matched yet");
+  if (det->lazy)
+    return fl_set_error(ctx, FL_ERR_STATE, "the last batch (fl_recognize_*) quantised its finer levels only around the candidates; "
+                                           "use fl_match_frame, or FL_EAGER_FRONTEND=1, for whole quantised pyramids");
   FL_HIP(ctx, hipSetDevice(ctx->device));
   for (int l = 0; l < det->L; ++l)
     for (int m = 0; m < det->M; ++m) {

@@ -59,7 +59,7 @@ extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t
   }
   det->have_times = true;
   FL_HIP(ctx, hipEventRecord(det->ev[0], ctx->stream));
-  int rc = fl_launch_frontend(det, n_frames, bgr_base, bgr_stride, depth_base, depth_stride);
+  int rc = fl_launch_frontend(det, n_frames, bgr_base, bgr_stride, depth_base, depth_stride, true);
   if (rc) return rc;
   rc = fl_launch_match_core(det, n_frames, params->matching_threshold);
   if (rc) return rc;
@@ -91,6 +91,10 @@ extern "C" int fl_recognize_collect(fl_detector *det, int n_frames, fl_recogniti
     t.linmem_ms = el(1, 2);
     t.scan_ms = el(2, 3);
     t.refine_ms = el(3, 4);
+    if (det->lazy) {
+      for (int l = 0; l + 1 < det->L; ++l) t.lazy_frontend_ms += el(8 + 2 * l, 9 + 2 * l);
+      t.refine_ms -= t.lazy_frontend_ms;
+    }
     t.sort_ms = el(4, 5);
     t.icp_ms = el(5, 6);
     t.total_ms = el(0, 6);
@@ -128,7 +132,7 @@ extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uin
   FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_depth, depth, (size_t)det->w0 * det->h0 * 2, kind, ctx->stream));
   det->have_times = false;
   const uint16_t *d_depth = (const uint16_t *)(det->d_ws + det->off_depth);
-  int rc = fl_launch_frontend(det, 1, det->d_ws + det->off_bgr, det->ws_stride, d_depth, det->ws_stride);
+  int rc = fl_launch_frontend(det, 1, det->d_ws + det->off_bgr, det->ws_stride, d_depth, det->ws_stride, true);
   if (rc) return rc;
   rc = fl_launch_match_core(det, 1, params->matching_threshold);
   if (rc) return rc;

@@ -267,6 +267,10 @@ typedef struct {
   float frontend_ms, linmem_ms, scan_ms, refine_ms, sort_ms, backproject_ms, icp_ms, total_ms;
   int32_t icp_iters_total, icp_launches;
   double scan_algorithmic_bytes;
+  float lazy_frontend_ms;   /* fl_recognize_*: colour quantisation + spread of the finer levels, computed after the scan
+                               and only in the tiles the candidates touch (0 when FL_EAGER_FRONTEND=1: then part of
+                               frontend_ms / linmem_ms).  refine_ms excludes it. */
+  float reserved0;
 } fl_stage_times;
 int  fl_last_stage_times(fl_detector *det, fl_stage_times *out);
 

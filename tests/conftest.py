@@ -9,6 +9,10 @@ import pytest
 import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# fl_recognize_* compute the finer pyramid levels only in the tiles the candidates can touch.  Under test, everything
+# outside those tiles is filled with 0xFF first, so a read the tile marking did not foresee cannot go unnoticed.
+os.environ.setdefault("FL_DEV_POISON", "1")
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)

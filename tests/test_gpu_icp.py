@@ -319,3 +319,43 @@ def test_point_to_plane_recognition_improves_the_pose(ctx, oracle):
         assert np.linalg.norm(b["pose"][:3, 3] - sc["t_true"]) <= max(1.0, np.linalg.norm(a["pose"][:3, 3] - sc["t_true"]))
     assert np.array_equal(pl[0]["pose"], pl[1]["pose"])
     det.close()
+
+
+# ---- lazy fine levels: fl_recognize_* quantise / spread the finer levels only in the tiles the candidates touch ----
+@pytest.mark.parametrize("levels,T", [(2, [5, 8]), (3, [5, 8, 4])])
+def test_lazy_fine_levels_equal_eager_and_oracle(ctx, oracle, levels, T, monkeypatch):
+    """Same results with the finer levels computed lazily (default) and eagerly (FL_EAGER_FRONTEND=1), for frames
+    whose object sits mid-image, is pushed against each border (patches that leave their linear memory mark the whole
+    frame) or is absent; conftest.py poisons everything outside the marked tiles."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=levels, seed=11, n_views=5, n_random=25)
+    frames_b, frames_d = [sc["bgr"]], [sc["depth"]]
+    for sh in (-200, 230):
+        frames_b.append(np.roll(sc["bgr"], sh, axis=1)); frames_d.append(np.roll(sc["depth"], sh, axis=1))
+    for sh in (-150, 170):
+        frames_b.append(np.roll(sc["bgr"], sh, axis=0)); frames_d.append(np.roll(sc["depth"], sh, axis=0))
+    frames_b.append(np.full_like(sc["bgr"], 90)); frames_d.append(np.full_like(sc["depth"], 1200))
+    results = {}
+    for mode in ("lazy", "eager"):
+        if mode == "eager":
+            monkeypatch.setenv("FL_EAGER_FRONTEND", "1")
+        det = api.Detector(ctx, 2, T)
+        det.add_class(sc["bank"])
+        det.finalize(640, 480, max_batch=len(frames_b))
+        results[mode] = det.recognize_batch(frames_b, frames_d, sc["K"], 70.0, 10, 0.5, 0.01)
+        t = det.stage_times()
+        assert (t["lazy_frontend_ms"] > 0) == (mode == "lazy")
+        if mode == "lazy":
+            with pytest.raises(api.FealessError):            # no whole quantised pyramid after a lazy batch
+                det.last_quantized()
+        det.close()
+    n_found = 0
+    for i, (a, b) in enumerate(zip(results["lazy"], results["eager"])):
+        exp = oracle.recognition(frames_b[i], frames_d[i], sc["K"], T, sc["bank"], 70.0, 10, 0.5, 0.01)
+        for g in (a, b):
+            assert g["status"] == 0 and g["found"] == exp["found"] and g["n_matches"] == exp["n_matches"], i
+            if exp["found"]:
+                assert g["best"]["x"] == exp["best"]["x"] and g["best"]["y"] == exp["best"]["y"]
+                assert g["best"]["template_id"] == exp["best"]["template_id"] and g["best"]["similarity"] == exp["best"]["similarity"]
+                assert np.array_equal(_bits(g["pose"]), _bits(exp["pose"]))
+        n_found += exp["found"]
+    assert n_found >= 2

@@ -8,6 +8,7 @@ import torch  # noqa: F401  (HIP runtime first)
 import oracle_py as O
 from fealess_amd import api, synth, _lib as L
 
+os.environ.setdefault("FL_DEV_POISON", "1")   # lazy fine levels: poison what the tile marking leaves out
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 ctx = api.Context(0)
 t0 = time.time()
