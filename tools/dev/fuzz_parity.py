@@ -60,13 +60,22 @@ while time.time() - t0 < budget:
             ok = ok and np.array_equal(ctx.resize_linear(bgr, dw, dh), O.resize_linear_u8(bgr, dw, dh)) and \
                 np.array_equal(ctx.resize_linear(dep, dw, dh), O.resize_linear_u16(dep, dw, dh))
             stats["frontend"] += 1
-        elif kind == 2:    # whole Recognition on a random synthetic scene
-            sc = synth.recognition_scene(lambda b, d, l: O.quantize_pyramid(b, d, l), levels=2, seed=seed, n_views=3, n_random=10)
-            det = api.Detector(ctx, 2, [5, 8]); det.add_class(sc["bank"]); det.finalize(640, 480)
+        elif kind == 2:    # whole Recognition (lazy fine levels, poisoned outside the marked tiles) on random scenes
+            lv = int(rng.integers(2, 4))
+            T = [[5, 8], [5, 8, 4]][lv - 2]
+            sc = synth.recognition_scene(lambda b, d, l: O.quantize_pyramid(b, d, l), levels=lv, seed=seed, n_views=3, n_random=10)
+            det = api.Detector(ctx, 2, T); det.add_class(sc["bank"]); det.finalize(640, 480, max_batch=2)
             it = int(rng.integers(1, 12))
-            r = det.recognize_batch([sc["bgr"]], [sc["depth"]], sc["K"], 70.0, it, 0.3, 0.01)[0]
-            e = O.recognition(sc["bgr"], sc["depth"], sc["K"], [5, 8], sc["bank"], 70.0, it, 0.3, 0.01)
-            ok = r["found"] == e["found"] and r["n_matches"] == e["n_matches"] and (not e["found"] or np.array_equal(bits(r["pose"]), bits(e["pose"])))
+            thr = float(rng.choice([60.0, 70.0, 80.0]))
+            ax, sh = int(rng.integers(0, 2)), int(rng.integers(-300, 300))
+            fb = [sc["bgr"], np.roll(sc["bgr"], sh, axis=ax)]
+            fd = [sc["depth"], np.roll(sc["depth"], sh, axis=ax)]
+            rs = det.recognize_batch(fb, fd, sc["K"], thr, it, 0.3, 0.01)
+            ok = True
+            for b_, d_, r in zip(fb, fd, rs):
+                e = O.recognition(b_, d_, sc["K"], T, sc["bank"], thr, it, 0.3, 0.01)
+                ok = ok and r["found"] == e["found"] and r["n_matches"] == e["n_matches"] and \
+                    (not e["found"] or np.array_equal(bits(r["pose"]), bits(e["pose"])))
             det.close()
             stats["recognition"] += 1
         elif kind == 4:    # template extraction (addTemplate) on a random view, with / without mask, 1-3 levels
