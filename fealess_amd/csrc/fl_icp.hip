@@ -43,6 +43,9 @@
 #define FL_ICP_WPE 5               // waves per SIMD the recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96):
                                   // measured +4 % frames/s at 5 workgroups per CU (LDS: 5 x 27 KB)
 #endif
+#ifndef FL_ICP_FAST_WPE
+#define FL_ICP_FAST_WPE 1          // minimum waves per SIMD the FL_ICP_FAST kernel is compiled for
+#endif
 #ifndef FL_ICP_PLANE_WPE
 #define FL_ICP_PLANE_WPE 3         // minimum waves per SIMD the point-to-plane kernel is compiled for (168 VGPRs; measured 1: 45.5, 3: 41.8, 4: 43.0 ms)
 #endif
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : 1), MODE == FL_ICP_PARITY ? FL_ICP_WPE : 4))) void k_icp_pipeline(IcpArgs a)
+__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE), MODE == FL_ICP_PARITY ? FL_ICP_WPE : 4))) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
