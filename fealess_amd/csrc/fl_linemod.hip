@@ -328,14 +328,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
   for (int m = 0; m < a.M; ++m) {
     const FlScanHdr h = a.hdr[g * a.M + m];
     nf += h.nf;
-    if (j0 >= h.P) continue;
-    const uint8_t *lm = ws + a.lm_off[m] + j0;
+    if (chunk * 1024 >= h.P) continue;                  // wave-uniform; lanes past P load along (masked below): the
+                                                       // next lane's first dword is this lane's bytes 16..19
+    const uint8_t *lm_u = ws + a.lm_off[m] + chunk * 1024;   // lane 0's bytes: wave-uniform
+    const uint8_t *lm = lm_u + lane * 16;
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const uint32_t *offs = a.offs + h.off_begin;
     // A feature's 16 bytes start at an arbitrary byte.  A byte-aligned 16-byte load costs ~2.4x a 4-byte aligned one
     // on gfx950 (tools/dev/ldwidth.hip) and this loop is bound by exactly those loads, so each feature is fetched as
     // an aligned 16 + 4 bytes and shifted into place with four v_alignbyte (the misalignment is wave-uniform).
-    const unsigned lm_mis = (unsigned)(size_t)lm & 3u;    // same for every lane: j0 is a multiple of 16
+    // The extra 4 bytes are the next lane's first dword: one DPP wave shift instead of a second vector load; lane 63's
+    // come from a wave-uniform address, i.e. a scalar load.
+    const unsigned lm_mis = (unsigned)(size_t)lm_u & 3u;  // same for every lane (lane * 16): keep it a scalar
     for (int k = 0; k < h.n_pad; k += 8) {
       uint4 v[8];
       uint32_t e[8];
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
         mis[u] = (lm_mis + off) & 3u;
         const uint8_t *pa = lm + off - mis[u];             // 4-byte aligned
         v[u] = *(const uint4 *)__builtin_assume_aligned(pa, 4);
-        e[u] = *(const uint32_t *)(pa + 16);
+        const uint32_t tail = *(const uint32_t *)__builtin_assume_aligned(lm_u + off - mis[u] + 1024, 4);
+        e[u] = (uint32_t)__builtin_amdgcn_update_dpp((int)tail, (int)v[u].x, 0x130, 0xF, 0xF, false);   // wave_shl:1
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
