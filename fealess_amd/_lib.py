@@ -107,6 +107,8 @@ SIGNATURES = {
                                  C.POINTER(RecognitionParams)]),
     "fl_recognize_collect": (_I, [_P, _I, _P]),
     "fl_recognize_topk": (_I, [_P, _P, _P, _I, C.POINTER(Intrinsics), C.POINTER(RecognitionParams), _I, _P, C.POINTER(_I)]),
+    "fl_recognize_batch_topk": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, C.POINTER(Intrinsics), C.POINTER(RecognitionParams), _I, _P,
+                                     C.POINTER(_I)]),
     "fl_nms": (_I, [_P, _I, _F, C.POINTER(_I), C.POINTER(_I)]),
     "fl_export_topk": (_I, [_P, _I, _I, _I, _P]),
     "fl_merge_topk": (_I, [_P, _I, _P, _I]),

@@ -293,6 +293,21 @@ class Detector:
         self._last_topk = res
         return [recognition_result_to_dict(res[i]) for i in range(n.value)]
 
+    def recognize_batch_topk(self, bgrs, depths, K, k, threshold=75.0, icp_it_thr=10, dist_mean_thr=0.5, dist_diff_thr=0.01,
+                             mode=L.FL_ICP_PARITY):
+        """recognize_topk for a batch: list (per frame) of lists of result dicts (n_frames * k ICP workgroups, one launch)."""
+        n = len(bgrs)
+        bs = [np.ascontiguousarray(b, np.uint8) for b in bgrs]
+        ds = [np.ascontiguousarray(d, np.uint16) for d in depths]
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        dp = (C.c_void_p * n)(*[d.ctypes.data for d in ds])
+        kk = L.Intrinsics(self.w0, self.h0, *K)
+        p = self._params(threshold, icp_it_thr, dist_mean_thr, dist_diff_thr, mode)
+        res = (L.RecognitionResult * (n * k))()
+        cnt = (C.c_int * n)()
+        self.ctx.check(self.lib.fl_recognize_batch_topk(self.h, n, bp, dp, L.FL_MEM_HOST, C.byref(kk), C.byref(p), k, res, cnt))
+        return [[recognition_result_to_dict(res[f * k + r]) for r in range(cnt[f])] for f in range(n)]
+
     def nms(self, n, th_obj_dist):
         """nonMaximumSuppression (ICP/NMS.cpp:6-40) over the first n hypotheses of the last recognize_topk call."""
         win = (C.c_int * max(1, n))()

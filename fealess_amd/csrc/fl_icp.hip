@@ -1486,10 +1486,10 @@ extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const 
 }
 
 // batch: one workgroup per frame of the detector workspace
-// Multi-hypothesis refinement of ONE frame: the first `k` matches of frame 0 are refined by k
-// workgroups of the same kernel, each with an ICP workspace of its own in `ws` (k * fl_icp_ws_bytes(n_pts_max)).
-int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, const fl_recognition_params *p, const uint16_t *depth,
-                             uint8_t *ws, fl_recognition_result *d_results)
+// Multi-hypothesis refinement: the first `k` matches of each of n_frames frames are refined by
+// n_frames * k workgroups of the same kernel, each with an ICP workspace of its own in `ws`.
+int fl_launch_detection_topk(fl_detector *det, int n_frames, int k, const fl_intrinsics *K, const fl_recognition_params *p,
+                             const uint16_t *depth, size_t depth_stride, uint8_t *ws, fl_recognition_result *d_results)
 {
   fl_context *ctx = det->ctx;
   IcpArgs a;
@@ -1512,7 +1512,7 @@ int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, co
   a.frame_stride = det->ws_stride;
   a.ranks = k;
   a.scene_base = depth;
-  a.scene_stride = 0;
+  a.scene_stride = depth_stride;
   a.off_count = det->off_count;
   a.off_match = det->off_match;
   a.pyr = det->d_pyr;
@@ -1520,7 +1520,7 @@ int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, co
   a.poses = det->d_poses;
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = d_results;
-  return icp_launch(ctx, k, a);
+  return icp_launch(ctx, n_frames * k, a);
 }
 
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *p,

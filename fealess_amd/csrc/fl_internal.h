@@ -177,8 +177,8 @@ int fl_launch_spread_tiles(fl_context *ctx, const uint8_t *quant, size_t quant_s
                            int n_frames, int w, int h, int T, const uint32_t *tiles, size_t tiles_stride);
 // icp
 size_t fl_icp_ws_bytes(int n_pts_max);
-int fl_launch_detection_topk(fl_detector *det, int k, const fl_intrinsics *K, const fl_recognition_params *p, const uint16_t *depth,
-                             uint8_t *ws, fl_recognition_result *d_results);
+int fl_launch_detection_topk(fl_detector *det, int n_frames, int k, const fl_intrinsics *K, const fl_recognition_params *p,
+                             const uint16_t *depth, size_t depth_stride, uint8_t *ws, fl_recognition_result *d_results);
 size_t fl_icp_ws_bytes(int n_pts_max);
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K,
                               const fl_recognition_params *p, const uint16_t *depth,

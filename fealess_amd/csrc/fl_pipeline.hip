@@ -21,9 +21,10 @@ static bool uniform_stride(const void *const *ptrs, int n, size_t min_bytes, siz
   return true;
 }
 
-extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr,
-                                   const uint16_t *const *depth, int mem, const fl_intrinsics *K,
-                                   const fl_recognition_params *params)
+// argument checks, frame staging, front-end and Detector::match of a batch; the depth frames' device location comes back
+static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth, int mem,
+                           const fl_intrinsics *K, const fl_recognition_params *params, const uint16_t **depth_base_out,
+                           size_t *depth_stride_out)
 {
   if (!det || !bgr || !K || !params || n_frames <= 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
@@ -63,6 +64,20 @@ extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t
   if (rc) return rc;
   rc = fl_launch_match_core(det, n_frames, params->matching_threshold);
   if (rc) return rc;
+  *depth_base_out = depth_base;
+  *depth_stride_out = depth_stride;
+  return FL_OK;
+}
+
+extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr,
+                                   const uint16_t *const *depth, int mem, const fl_intrinsics *K,
+                                   const fl_recognition_params *params)
+{
+  const uint16_t *depth_base = nullptr;
+  size_t depth_stride = 0;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride);
+  if (rc) return rc;
+  fl_context *ctx = det->ctx;
   FL_HIP(ctx, hipMemsetAsync(det->d_results, 0, sizeof(fl_recognition_result) * (size_t)n_frames, ctx->stream));
   rc = fl_launch_detection_batch(det, n_frames, K, params, depth_base, depth_stride);
   if (rc) return rc;
@@ -141,7 +156,7 @@ extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uin
   if ((rc = fl_scratch(ctx, icp_bytes + fl_align(res_bytes, 256), &sv))) return rc;
   fl_recognition_result *d_res = (fl_recognition_result *)((uint8_t *)sv + icp_bytes);
   FL_HIP(ctx, hipMemsetAsync(d_res, 0, res_bytes, ctx->stream));
-  if ((rc = fl_launch_detection_topk(det, k, K, params, d_depth, (uint8_t *)sv, d_res))) return rc;
+  if ((rc = fl_launch_detection_topk(det, 1, k, K, params, d_depth, 0, (uint8_t *)sv, d_res))) return rc;
   FL_HIP(ctx, hipMemcpyAsync(results, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   det->last_batch = 1;
@@ -149,6 +164,42 @@ extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uin
   if (results[0].status == FL_ERR_OVERFLOW) return fl_set_error(ctx, FL_ERR_OVERFLOW, "more than %d candidates in the frame", det->cap);
   const int n = results[0].n_matches < k ? results[0].n_matches : k;
   *n_results = n < 0 ? 0 : n;
+  return FL_OK;
+}
+
+// The same for a whole batch: n_frames * k ICP workgroups in one launch.  results[f * k + r] is hypothesis r of frame f,
+// n_results[f] = min(k, matches of frame f).
+extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                                       int mem, const fl_intrinsics *K, const fl_recognition_params *params, int k,
+                                       fl_recognition_result *results, int *n_results)
+{
+  if (!results || !n_results || k < 1 || k > 1024) return FL_ERR_INVALID;
+  if (det && det->M != 2) return fl_set_error(det->ctx, FL_ERR_INVALID, "needs the colour + depth modalities");
+  const uint16_t *depth_base = nullptr;
+  size_t depth_stride = 0;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride);
+  if (rc) return rc;
+  fl_context *ctx = det->ctx;
+  det->have_times = false;
+  const size_t jobs = (size_t)n_frames * k, ws_one = fl_align(fl_icp_ws_bytes(det->n_pts_max), 256);
+  const size_t icp_bytes = ws_one * jobs, res_bytes = sizeof(fl_recognition_result) * jobs;
+  if (jobs > (1u << 20) || icp_bytes > ((size_t)96 << 30))
+    return fl_set_error(ctx, FL_ERR_INVALID, "%d frames x %d hypotheses need %zu MB of ICP workspaces", n_frames, k, icp_bytes >> 20);
+  void *sv = nullptr;
+  if ((rc = fl_scratch(ctx, icp_bytes + fl_align(res_bytes, 256), &sv))) return rc;
+  fl_recognition_result *d_res = (fl_recognition_result *)((uint8_t *)sv + icp_bytes);
+  FL_HIP(ctx, hipMemsetAsync(d_res, 0, res_bytes, ctx->stream));
+  if ((rc = fl_launch_detection_topk(det, n_frames, k, K, params, depth_base, depth_stride, (uint8_t *)sv, d_res))) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(results, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  det->last_batch = n_frames;
+  det->last_from_images = true;
+  for (int f = 0; f < n_frames; ++f) {
+    const fl_recognition_result &r0 = results[(size_t)f * k];
+    if (r0.status == FL_ERR_OVERFLOW) return fl_set_error(ctx, FL_ERR_OVERFLOW, "frame %d: more than %d candidates", f, det->cap);
+    const int n = r0.n_matches < k ? r0.n_matches : k;
+    n_results[f] = n < 0 ? 0 : n;
+  }
   return FL_OK;
 }
 

@@ -249,6 +249,11 @@ int  fl_recognize_collect(fl_detector *det, int n_frames, fl_recognition_result 
  * a hypothesis whose crop leaves the image has found = 0 and status = FL_ERR_ASSERT. */
 int  fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, const fl_intrinsics *K,
                        const fl_recognition_params *params, int k, fl_recognition_result *results, int *n_results);
+/* The same for a batch (n_frames * k ICP workgroups in one launch): results[f * k + r] (host) is hypothesis r of
+ * frame f, n_results[f] = min(k, matches of frame f).  Frame pointers as for fl_recognize_batch. */
+int  fl_recognize_batch_topk(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                             int mem, const fl_intrinsics *K, const fl_recognition_params *params, int k,
+                             fl_recognition_result *results, int *n_results);
 /* nonMaximumSuppression (ICP/NMS.cpp:6-40) over refined hypotheses in list order: winners[g] = index of the
  * hypothesis representing group g (translation closer than th_obj_dist to the group's current best). Host only. */
 int  fl_nms(const fl_recognition_result *objs, int n, float th_obj_dist, int *winners, int *n_winners);
