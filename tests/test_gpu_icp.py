@@ -363,17 +363,17 @@ def test_lazy_fine_levels_equal_eager_and_oracle(ctx, oracle, levels, T, monkeyp
 
 def test_batch_topk_equals_per_frame_topk(ctx, oracle):
     """fl_recognize_batch_topk = fl_recognize_topk frame by frame (n_frames * k ICP workgroups in one launch)."""
-    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=8, n_views=5, n_random=20)
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=21, n_views=6)
     frames_b = [sc["bgr"], np.roll(sc["bgr"], 40, axis=1), np.full_like(sc["bgr"], 90)]
     frames_d = [sc["depth"], np.roll(sc["depth"], 40, axis=1), np.full_like(sc["depth"], 1200)]
     det = api.Detector(ctx, 2, [5, 8])
     det.add_class(sc["bank"])
     det.finalize(640, 480, max_batch=3)
     k = 4
-    got = det.recognize_batch_topk(frames_b, frames_d, sc["K"], k, 65.0, 8, 0.0, -3.0e38)
+    got = det.recognize_batch_topk(frames_b, frames_d, sc["K"], k, 60.0, 8, 0.3, 0.01)
     assert len(got) == 3 and len(got[0]) >= 2 and got[2] == []
     for f in range(3):
-        one = det.recognize_topk(frames_b[f], frames_d[f], sc["K"], k, 65.0, 8, 0.0, -3.0e38)
+        one = det.recognize_topk(frames_b[f], frames_d[f], sc["K"], k, 60.0, 8, 0.3, 0.01)
         assert len(one) == len(got[f])
         for a, b in zip(one, got[f]):
             assert a["best"] == b["best"] and a["found"] == b["found"] and a["status"] == b["status"]
