@@ -204,8 +204,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
     if os.environ.get("FL_ICP_PHASES"):   # dev aid (tools/dev): a library built with -DFL_ICP_PHASES returns phase cycles in R
-        ph = np.array([[r.det.icp.R[k] for k in range(6)] for r in res]).mean(0)
-        print("icp phase Mcycles mean: grid %.2f A1 %.2f A2 %.2f svd %.2f B %.2f" % (ph[0] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6),
+        ph = np.array([[r.det.icp.R[k] for k in range(8)] for r in res]).mean(0)
+        print("icp phase Mcycles mean: grid %.2f A1 %.2f A2 %.2f svd %.2f B %.2f | before icp_run %.2f, whole kernel %.2f" %
+              (ph[0] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6),
               file=sys.stderr)
     found = sum(int(r.found) for r in res)
     iters = sum(int(r.det.icp.iters) for r in res if r.found)

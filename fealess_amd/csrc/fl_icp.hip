@@ -130,6 +130,7 @@ struct IcpShared {
   float sums[16];
   double dsum[ICP_BS / 64][32];   // [wave][scalar]
   int iscan[ICP_BS / 64 + 1];
+  int iscan2[2][ICP_BS / 64];          // crop_clouds: per-wave kept counts, double-buffered
   int ibase;
   float fred[4][ICP_BS / 64];
   int n, rect_m[4], rect_r[4], status, g;
@@ -139,7 +140,7 @@ struct IcpShared {
   alignas(16) float prod[2][15][ICP_TS];
   alignas(16) float dtile[2][ICP_TQ];
 #ifdef FL_ICP_PHASES
-  long long tacc[16], tlast;
+  long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
 #endif
 };
 
@@ -332,14 +333,26 @@ __device__ __forceinline__ float chain_sum(const float *tab, int n, int stride, 
 {
   float acc = 0.0f;
   if (active) {
+    // one memory round trip per 16 elements would be the whole cost: the next batch is in flight while this one is added
     const float *p = tab + k;
     int i = 0;
-    for (; i + 16 <= n; i += 16) {
-      float v[16];
+    float v[16], w[16];
+    if (n >= 16) {
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(i + u) * stride];
+      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)u * stride];
+    }
+    for (; i + 32 <= n; i += 16) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = p[(size_t)(i + 16 + u) * stride];
 #pragma unroll
       for (int u = 0; u < 16; ++u) acc += v[u];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = w[u];
+    }
+    if (i + 16 <= n) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += v[u];
+      i += 16;
     }
     for (; i < n; ++i) acc += p[(size_t)i * stride];
   }
@@ -761,6 +774,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
 #ifdef FL_ICP_PHASES
     for (int i = 0; i < 16; ++i) S.tacc[i] = 0;
     S.tlast = clock64();
+    S.tacc[6] = S.tlast - S.tkernel;
 #endif
   }
   __syncthreads();
@@ -1067,8 +1081,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     res->iters = S.iter;
     res->n_corr_last = S.n_corr;
 #ifdef FL_ICP_PHASES
-    // dev build only: phase cycles (grid, -, A1, A2, svd, B) of this workgroup instead of R
+    // dev build only: phase cycles (grid, -, A1, A2, svd, B, before icp_run, whole kernel) of this workgroup instead of R
     for (int i = 0; i < 6; ++i) res->R[i] = (float)S.tacc[i];
+    res->R[6] = (float)S.tacc[6];
+    res->R[7] = (float)(clock64() - S.tkernel);
 #endif
   }
   __syncthreads();
@@ -1113,14 +1129,19 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
   const float inv_fx = 1.0f / a.fx, inv_fy = 1.0f / a.fy;                        // depth_to_3d.cpp:103-104
   const float minv_fx = 1.0f / 608.f, minv_fy = 1.0f / 608.f;                   // initInternalMat common.cpp:358
   const float zs = (float)(1 / 1000.0);
-  if (threadIdx.x == 0) S.ibase = 0;
+  // Row-major compaction of the paired-valid pixels.  Per 256 pixels: rank inside the wave by ballot + mbcnt, the four
+  // wave counts through a double-buffered LDS slot -- ONE barrier per step (the block-wide scan it replaces took
+  // five, and with 5 workgroups per CU the barriers were the cost); every thread keeps the running total itself.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const float inv_cw = 1.0f / (float)cw;                   // p / cw below: exact for p < 2^20, cw <= 2^10 (see div_small)
+  int kept_before = 0, step = 0;
   __syncthreads();
-  for (int base = 0; base < np; base += blockDim.x) {
+  for (int base = 0; base < np; base += blockDim.x, ++step) {
     const int p = base + threadIdx.x;
     float A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
     int keep = 0;
     if (p < np) {
-      const int y = p / cw, x = p - y * cw;
+      const int y = np < (1 << 20) && cw <= 1024 ? (int)(((float)p + 0.5f) * inv_cw) : p / cw, x = p - y * cw;
       const int sx = rr[0] + x, sy = rr[1] + y, mx = rm[0] + x, my = rm[1] + y;
       const unsigned ds = scene[(size_t)sy * a.w + sx];
       unsigned dm = model[(size_t)my * a.w + mx];
@@ -1138,10 +1159,15 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
       B[2] = zmf * 1000;
       keep = vvalid(A[2]) && vvalid(B[2]);                                        // matToVec common.cpp:382-405
     }
-    int total;
-    const int ex = block_excl_scan(S, keep, &total);
+    const unsigned long long bal = __ballot(keep);
+    const int in_wave = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+    int *slot = S.iscan2[step & 1];
+    if (lane == 0) slot[wv] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int i = 0; i < nwv; ++i) { const int c = slot[i]; before += i < wv ? c : 0; total += c; }
     if (keep) {
-      const int k = S.ibase + ex;
+      const int k = kept_before + before + in_wave;
       ref[3 * k] = A[0]; ref[3 * k + 1] = A[1]; ref[3 * k + 2] = A[2];
       mod[3 * k] = B[0]; mod[3 * k + 1] = B[1]; mod[3 * k + 2] = B[2];
       if (nrm) {
@@ -1150,11 +1176,10 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
         nrm[3 * k] = nv[0]; nrm[3 * k + 1] = nv[1]; nrm[3 * k + 2] = nv[2];
       }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) S.ibase += total;
-    __syncthreads();
+    kept_before += total;
   }
-  return S.ibase;
+  __syncthreads();                                         // the clouds are complete for every thread
+  return kept_before;
 }
 
 // icpCloudToCloud_Ex on clouds the host staged in the workspace (fl_icp)
@@ -1173,6 +1198,9 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
+#ifdef FL_ICP_PHASES
+  if (threadIdx.x == 0) S.tkernel = clock64();
+#endif
   const int job = blockIdx.x, frame = a.job.kind == 0 ? job / a.ranks : job, rank = a.job.kind == 0 ? job % a.ranks : 0;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)job * a.ws_stride;
@@ -1247,10 +1275,27 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
   if (MODE == FL_ICP_PARITY) {
-    if (threadIdx.x < 64) {
-      const int k = threadIdx.x;
-      const float acc = chain_sum(k < 3 ? mod : ref, np, 3, k < 3 ? k : k - 3, k < 6);
-      if (k < 6) S.sums[k] = acc;
+    // getMean x2 as six float32 chains in index order, fed like phase A2: waves 1..3 load 192 rows per tile
+    // (coalesced 12-byte loads) into the LDS tiles, lanes 0..5 of wave 0 add the previous tile
+    {
+      const int slot = (int)threadIdx.x - 64, ntiles = (np + ICP_TQ - 1) / ICP_TQ;
+      float acc = 0.0f;
+      for (int t = 0; t < ntiles; ++t) {
+        if (slot >= 0) {
+          const int i = t * ICP_TQ + slot;
+          F3 m3 = {0.f, 0.f, 0.f}, r3 = {0.f, 0.f, 0.f};
+          if (i < np) { m3 = ld3_u32(mod, i); r3 = ld3_u32(ref, i); }
+          float (*tile)[ICP_TS] = S.prod[t & 1];
+          tile[0][slot] = m3.x; tile[1][slot] = m3.y; tile[2][slot] = m3.z;
+          tile[3][slot] = r3.x; tile[4][slot] = r3.y; tile[5][slot] = r3.z;
+        } else if (t > 0 && threadIdx.x < 6) {
+          acc = chain_tile(S.prod[(t - 1) & 1][threadIdx.x], min(ICP_TQ, np - (t - 1) * ICP_TQ), acc);
+        }
+        __syncthreads();
+      }
+      if (ntiles > 0 && threadIdx.x < 6)
+        acc = chain_tile(S.prod[(ntiles - 1) & 1][threadIdx.x], min(ICP_TQ, np - (ntiles - 1) * ICP_TQ), acc);
+      if (threadIdx.x < 6) S.sums[threadIdx.x] = acc;
     }
     __syncthreads();
     for (int k = 0; k < 3; ++k) { mc[k] = S.sums[k]; rc[k] = S.sums[3 + k]; }
