@@ -501,21 +501,38 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
       atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
   }
   __syncthreads();
-  // exclusive scan of the counts -> cell_start
-  if (threadIdx.x == 0) S.ibase = 0;
-  __syncthreads();
-  for (int base = 0; base < ncell; base += blockDim.x) {
-    const int i = base + threadIdx.x;
-    const int v = i < ncell ? cell_cur[i] : 0;
-    int total;
-    const int ex = block_excl_scan(S, v, &total);
-    if (i < ncell) cell_start[i] = S.ibase + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) S.ibase += total;
-    __syncthreads();
+  // exclusive scan of the counts -> cell_start (and cell_cur, the scatter cursors): four consecutive cells per thread,
+  // a shuffle scan inside the wave, the wave totals through a double-buffered LDS slot -- one barrier per 1024 cells
+  {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    int run = 0, step = 0;
+    for (int base = 0; base < ncell; base += 4 * blockDim.x, ++step) {
+      const int i0 = base + 4 * threadIdx.x;
+      int c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = i0 + u < ncell ? cell_cur[i0 + u] : 0;
+      const int mine = (c[0] + c[1]) + (c[2] + c[3]);
+      int inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+      }
+      int *slot = S.iscan2[step & 1];
+      if (lane == 63) slot[wv] = inc;
+      __syncthreads();
+      int before = 0, total = 0;
+      for (int w = 0; w < nwv; ++w) { const int t = slot[w]; before += w < wv ? t : 0; total += t; }
+      int ex = run + before + inc - mine;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u < ncell) { cell_start[i0 + u] = ex; cell_cur[i0 + u] = ex; }
+        ex += c[u];
+      }
+      run += total;
+    }
+    if (threadIdx.x == 0) { cell_start[ncell] = run; S.nsorted = run; }
   }
-  if (threadIdx.x == 0) { cell_start[ncell] = S.ibase; S.nsorted = S.ibase; }
-  for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = cell_start[i];
   __syncthreads();
   for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
     const F3 p3 = ld3_u32(ref, i);
