@@ -450,7 +450,7 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   }
   det->off_tmp = take((size_t)w0 * h0);
   det->off_count = take(256);
-  det->off_tiles = take((size_t)(L > 1 ? L - 1 : 1) * 2 * FL_TILE_WORDS * sizeof(uint32_t));
+  det->off_tiles = take((size_t)(L > 1 ? L - 1 : 1) * FL_TILE_BLOCK_WORDS * sizeof(uint32_t));
   det->lazy_capable = L > 1;
   for (int l = 0; l + 1 < L; ++l) {
     const FlLevelGeom &g = det->geom[l];

@@ -108,9 +108,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
   const int item = blockIdx.x * 4 + wave;
   if (item >= nstrips * nchunks) return;
   const int strip = item % nstrips, chunk = item / nstrips;
-  if (tiles) {             // lazy fine level: only the tiles whose pixels some candidate's spread bytes read
+  int row_lo = 0, row_hi = h - 1;
+  if (tiles) {             // lazy fine level: only the tiles (and, inside a tile, the rows) some candidate's spreads read
+    const uint32_t *tb = tiles + (size_t)blockIdx.z * tiles_stride;
     const int t = chunk * nstrips + strip;
-    if (!((tiles[(size_t)blockIdx.z * tiles_stride + (t >> 5)] >> (t & 31)) & 1u)) return;   // wave-uniform
+    if (!((tb[FL_TILE_WORDS + (t >> 5)] >> (t & 31)) & 1u)) return;                          // wave-uniform
+    const uint32_t rw = tb[2 * FL_TILE_WORDS + 32 * FL_TILE_WORDS + t];
+    row_lo = (int)(rw >> 16);
+    row_hi = (int)(rw & 0xFFFFu);
   }
   const uint8_t *src = bgr + (size_t)blockIdx.z * in_stride;
   uint8_t *out = dst + (size_t)blockIdx.z * out_stride;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
   // a sample requested outside the image is the sample at the clamped position -- for the blur's own
   // taps and for Sobel's BORDER_REPLICATE on the *smoothed* image alike (linemod.cpp:247-249)
   const int xc = clampi(x, 0, w - 1);
-  const int y0 = chunk * CQ_CH, y1 = min(h, y0 + CQ_CH);
+  const int y0 = max(chunk * CQ_CH, row_lo), y1 = min(min(h, chunk * CQ_CH + CQ_CH), row_hi + 1);
   const bool interior = __all(xc >= 3 && xc <= w - 5);
 
   int H[7][3];
@@ -593,7 +598,7 @@ int fl_launch_lazy_level(fl_detector *det, int n_frames, int level)
 {
   fl_context *ctx = det->ctx;
   const FlLevelGeom &g = det->geom[level];
-  const uint32_t *tiles = (const uint32_t *)(det->d_ws + det->off_tiles) + (size_t)level * 2 * FL_TILE_WORDS;
+  const uint32_t *tiles = (const uint32_t *)(det->d_ws + det->off_tiles) + (size_t)level * FL_TILE_BLOCK_WORDS;
   const size_t tstride = det->ws_stride / sizeof(uint32_t);
   if (det->poison_env) {   // dev aid: a byte read outside the marked tiles must not look plausible
     FL_HIP(ctx, hipMemset2DAsync(det->d_ws + g.quant_off[0], det->ws_stride, 0xFF, (size_t)g.w * g.h, n_frames, ctx->stream));
@@ -602,7 +607,7 @@ int fl_launch_lazy_level(fl_detector *det, int n_frames, int level)
   }
   int rc = launch_color_quantize(ctx, level == 0 ? det->lazy_bgr : det->d_ws + g.bgr_off, level == 0 ? det->lazy_bgr_stride : det->ws_stride,
                                  det->d_ws + g.quant_off[0], det->ws_stride, n_frames, g.w, g.h, 10.0f, nullptr,
-                                 tiles + FL_TILE_WORDS, tstride);
+                                 tiles, tstride);
   if (rc) return rc;
   for (int m = 0; m < det->M; ++m) {
     rc = fl_launch_spread_tiles(ctx, det->d_ws + g.quant_off[m], det->ws_stride, det->d_ws + g.spread_off[m], det->ws_stride, n_frames,

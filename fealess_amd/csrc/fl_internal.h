@@ -70,7 +70,11 @@ struct FlCand {          // a candidate / match in flight
 };
 
 #define FL_TILE 60                 // tile edge in pixels (= CQ_COLS = CQ_CH of k_color_quantize)
-#define FL_TILE_WORDS 64           // bitmap words per frame, level and kind: up to 2048 tiles
+#define FL_TILE_WORDS 16           // bitmap words per frame, level and kind: up to 512 tiles (1280x960: 352)
+// One block of uint32 per frame and fine level: bm[2][FL_TILE_WORDS] (kind 0: tiles whose spread bytes are read,
+// kind 1: tiles whose quantised pixels those spreads are made of), then rows[2][32 * FL_TILE_WORDS]: for a marked
+// tile (first needed image row << 16) | last needed image row.
+#define FL_TILE_BLOCK_WORDS (66 * FL_TILE_WORDS)
 #define FL_NUM_EVENTS 24
 
 struct FlLevelGeom {
@@ -127,7 +131,7 @@ struct fl_detector {
   // coarse scan produced.  Their colour quantisation and spread images are therefore computed after the scan and
   // only in the 60x60-pixel tiles the candidates' 16x16 patches can touch (k_mark_tiles).  Two bitmaps per frame
   // and fine level: tiles whose spread bytes are read, tiles whose quantised pixels those spreads read.
-  size_t off_tiles = 0;                  // [L-1][2][FL_TILE_WORDS] uint32 per frame
+  size_t off_tiles = 0;                  // [L-1][FL_TILE_BLOCK_WORDS] uint32 per frame
   bool lazy_capable = false;             // tile grid fits the bitmaps
   bool lazy = false;                     // this batch runs lazily (set by fl_launch_frontend)
   bool eager_env = false, poison_env = false;   // FL_EAGER_FRONTEND / FL_DEV_POISON (dev knobs, read at finalize)

@@ -158,7 +158,11 @@ __global__ __launch_bounds__(256) void k_spread(const uint8_t *__restrict__ quan
     for (int c = c0; c <= c1; ++c)
       for (int st = 0; st < nstrips; ++st) {
         const int t = c * nstrips + st;
-        if ((tf[t >> 5] >> (t & 31)) & 1u) { smin = min(smin, st); smax = max(smax, st); }
+        if (!((tf[t >> 5] >> (t & 31)) & 1u)) continue;
+        const uint32_t rw = tf[2 * FL_TILE_WORDS + t];     // rows of this tile that are read: does the strip touch them?
+        if ((int)(rw & 0xFFFFu) < y0 || (int)(rw >> 16) > y0 + RS - 1) continue;
+        smin = min(smin, st);
+        smax = max(smax, st);
       }
     if (smax < 0) return;                                  // workgroup-uniform
     lo4 = (smin * FL_TILE) >> 2;
@@ -582,11 +586,13 @@ __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
 __global__ __launch_bounds__(256) void k_mark_tiles(RefineArgs a, size_t off_tiles)
 {
   __shared__ uint32_t bm[2][FL_TILE_WORDS];
+  __shared__ int rlo[2][32 * FL_TILE_WORDS], rhi[2][32 * FL_TILE_WORDS];
   __shared__ int s_all;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int frame = blockIdx.x;
   uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
   for (int i = threadIdx.x; i < 2 * FL_TILE_WORDS; i += 256) bm[0][i] = 0;
+  for (int i = threadIdx.x; i < 2 * 32 * FL_TILE_WORDS; i += 256) { rlo[0][i] = 0xFFFF; rhi[0][i] = 0; }
   if (threadIdx.x == 0) s_all = 0;
   __syncthreads();
   const int n = min(*(const int *)(ws + a.off_count), a.cap);
@@ -635,22 +641,33 @@ __global__ __launch_bounds__(256) void k_mark_tiles(RefineArgs a, size_t off_til
 #pragma unroll
     for (int kind = 0; kind < 2; ++kind) {
       const int grow = kind ? T - 1 : 0;
-      const int s0 = x0 / FL_TILE, s1 = min(a.w - 1, x1 + grow) / FL_TILE, c0 = y0 / FL_TILE, c1 = min(a.h - 1, y1 + grow) / FL_TILE;
+      const int yb = min(a.h - 1, y1 + grow);
+      const int s0 = x0 / FL_TILE, s1 = min(a.w - 1, x1 + grow) / FL_TILE, c0 = y0 / FL_TILE, c1 = yb / FL_TILE;
       const int ns = s1 - s0 + 1, nt = ns * (c1 - c0 + 1);
       for (int t = lane; t < nt; t += 64) {
         const int c = t / ns, tile = (c0 + c) * nstrips + s0 + (t - c * ns);
         atomicOr(&bm[kind][tile >> 5], 1u << (tile & 31));
+        atomicMin(&rlo[kind][tile], max(y0, (c0 + c) * FL_TILE));
+        atomicMax(&rhi[kind][tile], min(yb, (c0 + c) * FL_TILE + FL_TILE - 1));
       }
     }
   }
   __syncthreads();
-  uint32_t *out = (uint32_t *)(ws + off_tiles) + (size_t)a.level * 2 * FL_TILE_WORDS;
+  uint32_t *out = (uint32_t *)(ws + off_tiles) + (size_t)a.level * FL_TILE_BLOCK_WORDS;
   const int ntiles = nstrips * nchunks;
+  const bool all = s_all != 0;
   for (int i = threadIdx.x; i < 2 * FL_TILE_WORDS; i += 256) {
     const int wd = i % FL_TILE_WORDS;
     uint32_t v = bm[0][i];
-    if (s_all) v = wd * 32 + 32 <= ntiles ? 0xFFFFFFFFu : (wd * 32 < ntiles ? (1u << (ntiles - wd * 32)) - 1u : 0u);
+    if (all) v = wd * 32 + 32 <= ntiles ? 0xFFFFFFFFu : (wd * 32 < ntiles ? (1u << (ntiles - wd * 32)) - 1u : 0u);
     out[i] = v;
+  }
+  for (int i = threadIdx.x; i < 2 * 32 * FL_TILE_WORDS; i += 256) {
+    const int tile = i % (32 * FL_TILE_WORDS);
+    uint32_t v = ((uint32_t)rlo[0][i] << 16) | (uint32_t)rhi[0][i];
+    if (all) v = (uint32_t)(a.h - 1);                       // rows 0 .. h-1: the consumers clip to their own tile
+    (void)tile;
+    out[2 * FL_TILE_WORDS + i] = v;
   }
 }
 
