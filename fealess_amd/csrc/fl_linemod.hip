@@ -1035,7 +1035,10 @@ extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16
   // keeps the candidate buffer untouched in practice (counters are reset by the launcher)
   det->have_times = false;
   FL_HIP(ctx, hipMemsetAsync(det->d_ws + det->off_count, 0, 16, ctx->stream));
+  const bool was_lazy = det->lazy;       // no candidate survives 200 %: nothing of the finer levels is needed, and the
+  det->lazy = false;                     // batch's colour frames (lazy_bgr) may be gone by now
   rc = launch_scan_refine_sort(det, 1, 200.0f, (uint16_t *)d, first, count);
+  det->lazy = was_lazy;
   if (rc) return rc;
   FL_HIP(ctx, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
