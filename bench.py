@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-frames-steps", type=int, default=2,
+                    help="extra untimed-for-value steps with the frames in pinned HOST memory (upload inside the step): the "
+                         "PCIe-inclusive rate reported as pcie_inclusive (0 = skip)")
     ap.add_argument("--eager-frontend", action="store_true",
                     help="quantise and spread the finer pyramid levels in full before the scan (the reference's order) instead of "
                          "only in the tiles the scan's candidates touch; same results")
@@ -208,6 +211,26 @@ def main():
         print("icp phase Mcycles mean: grid %.2f A1 %.2f A2 %.2f svd %.2f B %.2f | before icp_run %.2f, whole kernel %.2f" %
               (ph[0] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6),
               file=sys.stderr)
+    pcie = None
+    if args.host_frames_steps > 0:
+        # informational: the same step with host frames (pinned), i.e. 1.54 MB per frame over PCIe inside the step
+        h_bgr = torch.from_numpy(bgrs).pin_memory()
+        h_depth = torch.from_numpy(depths.view(np.int16)).pin_memory()
+        hb = [h_bgr.data_ptr() + i * 640 * 480 * 3 for i in range(B)]
+        hd = [h_depth.data_ptr() + i * 640 * 480 * 2 for i in range(B)]
+        det.recognize_submit_host(hb, hd, K, params)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.host_frames_steps):
+            det.recognize_submit_host(hb, hd, K, params)
+        sync_all()
+        el_h = time.perf_counter() - t1
+        res_h = det.recognize_collect(B)
+        pcie = {"value": round(B * args.host_frames_steps * world / el_h, 1), "unit": "frames/s",
+                "ms_per_step": round(el_h / args.host_frames_steps * 1e3, 3), "steps": args.host_frames_steps,
+                "detections": f"{sum(int(r.found) for r in res_h)}/{B}",
+                "note": "frames uploaded from pinned host memory inside every step (2 strided H2D copies on a copy stream, "
+                        "double-buffered: batch i+1 uploads while batch i computes); never the headline value"}
     found = sum(int(r.found) for r in res)
     iters = sum(int(r.det.icp.iters) for r in res if r.found)
     npts = sum(int(r.det.n_points) for r in res if r.found)
@@ -262,6 +285,7 @@ def main():
                                       "lazy (tiles the scan's candidates touch; --eager-frontend for whole images)"},
             "ms_per_icp_iter": round(times["icp_ms"] / max(1, args.icp_iters), 5),
             "ms_per_icp_iter_per_frame_amortised": round(times["icp_ms"] / max(1, iters), 7),
+            "pcie_inclusive": pcie,
             "detections": f"{found}/{B}", "icp_iters_mean": round(iters / max(1, found), 2),
             "icp_points_mean": round(npts / max(1, found), 1),
             "stage_ms_last_step": {k: round(v, 4) for k, v in times.items() if k.endswith("_ms")},

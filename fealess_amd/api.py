@@ -322,6 +322,14 @@ class Detector:
         k = L.Intrinsics(self.w0, self.h0, *K)
         self.ctx.check(self.lib.fl_recognize_submit(self.h, n, bp, dp, L.FL_MEM_DEVICE, C.byref(k), C.byref(params)))
 
+    def recognize_submit_host(self, bgr_ptrs, depth_ptrs, K, params):
+        """Same as recognize_submit_device with host (ideally pinned) frame pointers: the upload is part of the call."""
+        n = len(bgr_ptrs)
+        bp = (C.c_void_p * n)(*bgr_ptrs)
+        dp = (C.c_void_p * n)(*depth_ptrs)
+        k = L.Intrinsics(self.w0, self.h0, *K)
+        self.ctx.check(self.lib.fl_recognize_submit(self.h, n, bp, dp, L.FL_MEM_HOST, C.byref(k), C.byref(params)))
+
     def recognize_collect(self, n):
         res = (L.RecognitionResult * n)()
         self.ctx.check(self.lib.fl_recognize_collect(self.h, n, res))

@@ -163,6 +163,13 @@ static void free_device_tables(fl_detector *det)
   det->h_results = nullptr;
   for (auto &e : det->ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (int b = 0; b < 2; ++b) {
+    if (det->d_in[b]) { (void)hipFree(det->d_in[b]); det->d_in[b] = nullptr; }
+    if (det->ev_up[b]) { (void)hipEventDestroy(det->ev_up[b]); det->ev_up[b] = nullptr; }
+    if (det->ev_read[b]) { (void)hipEventDestroy(det->ev_read[b]); det->ev_read[b] = nullptr; }
+    det->read_pending[b] = false;
+  }
+  if (det->copy_stream) { (void)hipStreamSynchronize(det->copy_stream); (void)hipStreamDestroy(det->copy_stream); det->copy_stream = nullptr; }
 }
 
 extern "C" void fl_detector_destroy(fl_detector *det)

@@ -136,6 +136,14 @@ struct fl_detector {
   bool lazy = false;                     // this batch runs lazily (set by fl_launch_frontend)
   bool eager_env = false, poison_env = false;   // FL_EAGER_FRONTEND / FL_DEV_POISON (dev knobs, read at finalize)
   const uint8_t *lazy_bgr = nullptr;     // level-0 colour frames of the batch in flight
+  // Host frames (fl_recognize_submit with FL_MEM_HOST): uploaded on a copy stream into one of two input buffers, so
+  // the upload of batch i+1 overlaps the compute of batch i (the compute stream waits on the upload's event, the
+  // copy stream on the event of the compute that last read the buffer it is about to overwrite).
+  hipStream_t copy_stream = nullptr;
+  uint8_t *d_in[2] = {nullptr, nullptr}; // max_batch * (bgr + depth) bytes each, allocated on first use
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr};
+  bool read_pending[2] = {false, false};
+  int in_flip = 0;
   size_t lazy_bgr_stride = 0;
   int n_pts_max = 0;
   int last_batch = 0;

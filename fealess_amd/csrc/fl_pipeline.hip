@@ -24,8 +24,9 @@ static bool uniform_stride(const void *const *ptrs, int n, size_t min_bytes, siz
 // argument checks, frame staging, front-end and Detector::match of a batch; the depth frames' device location comes back
 static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth, int mem,
                            const fl_intrinsics *K, const fl_recognition_params *params, const uint16_t **depth_base_out,
-                           size_t *depth_stride_out)
+                           size_t *depth_stride_out, int *host_buf_out)
 {
+  int host_buf = -1;     // the input buffer the batch was uploaded to (host frames), released by input_done()
   if (!det || !bgr || !K || !params || n_frames <= 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
   if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
@@ -50,12 +51,45 @@ static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const 
     bgr_base = bgr[0];
     bgr_stride = s1;
     if (det->M == 2) { depth_base = depth[0]; depth_stride = s2; }
+  } else if (mem == FL_MEM_HOST) {
+    // host frames: upload on the copy stream into the input buffer that is not being read (see fl_internal.h)
+    const int b = det->in_flip;
+    det->in_flip ^= 1;
+    const size_t depth_off = fl_align(bgr_bytes, 256), frame_in = depth_off + fl_align(depth_bytes, 256);
+    if (!det->copy_stream) FL_HIP(ctx, hipStreamCreateWithFlags(&det->copy_stream, hipStreamNonBlocking));
+    if (!det->d_in[b]) {
+      FL_HIP(ctx, hipMalloc((void **)&det->d_in[b], frame_in * (size_t)det->max_batch));
+      FL_HIP(ctx, hipEventCreateWithFlags(&det->ev_up[b], hipEventDisableTiming));
+      FL_HIP(ctx, hipEventCreateWithFlags(&det->ev_read[b], hipEventDisableTiming));
+    }
+    if (det->read_pending[b]) FL_HIP(ctx, hipStreamWaitEvent(det->copy_stream, det->ev_read[b], 0));
+    size_t hs1 = 0, hs2 = 0;
+    if (n_frames > 1 && uniform_stride((const void *const *)bgr, n_frames, bgr_bytes, &hs1) &&
+        (det->M < 2 || uniform_stride((const void *const *)depth, n_frames, depth_bytes, &hs2))) {
+      // frames at a regular pitch (one host array): one strided copy per modality instead of one per frame
+      FL_HIP(ctx, hipMemcpy2DAsync(det->d_in[b], frame_in, bgr[0], hs1, bgr_bytes, n_frames, hipMemcpyHostToDevice, det->copy_stream));
+      if (det->M == 2)
+        FL_HIP(ctx, hipMemcpy2DAsync(det->d_in[b] + depth_off, frame_in, depth[0], hs2, depth_bytes, n_frames, hipMemcpyHostToDevice,
+                                     det->copy_stream));
+    } else {
+      for (int i = 0; i < n_frames; ++i) {
+        uint8_t *dst = det->d_in[b] + (size_t)i * frame_in;
+        FL_HIP(ctx, hipMemcpyAsync(dst, bgr[i], bgr_bytes, hipMemcpyHostToDevice, det->copy_stream));
+        if (det->M == 2) FL_HIP(ctx, hipMemcpyAsync(dst + depth_off, depth[i], depth_bytes, hipMemcpyHostToDevice, det->copy_stream));
+      }
+    }
+    FL_HIP(ctx, hipEventRecord(det->ev_up[b], det->copy_stream));
+    FL_HIP(ctx, hipStreamWaitEvent(ctx->stream, det->ev_up[b], 0));
+    bgr_base = det->d_in[b];
+    bgr_stride = frame_in;
+    depth_base = (const uint16_t *)(det->d_in[b] + depth_off);
+    depth_stride = frame_in;
+    host_buf = b;
   } else {
-    const hipMemcpyKind kind = mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    for (int i = 0; i < n_frames; ++i) {
+    for (int i = 0; i < n_frames; ++i) {     // device frames at irregular addresses: gather them into the frame workspaces
       uint8_t *ws = det->d_ws + (size_t)i * det->ws_stride;
-      FL_HIP(ctx, hipMemcpyAsync(ws + det->off_bgr, bgr[i], bgr_bytes, kind, ctx->stream));
-      if (det->M == 2) FL_HIP(ctx, hipMemcpyAsync(ws + det->off_depth, depth[i], depth_bytes, kind, ctx->stream));
+      FL_HIP(ctx, hipMemcpyAsync(ws + det->off_bgr, bgr[i], bgr_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      if (det->M == 2) FL_HIP(ctx, hipMemcpyAsync(ws + det->off_depth, depth[i], depth_bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
   }
   det->have_times = true;
@@ -66,6 +100,17 @@ static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const 
   if (rc) return rc;
   *depth_base_out = depth_base;
   *depth_stride_out = depth_stride;
+  *host_buf_out = host_buf;
+  return FL_OK;
+}
+
+// after the last kernel that reads the batch's frames has been queued: the copy stream may reuse the buffer after it
+static int input_done(fl_detector *det, int host_buf)
+{
+  if (host_buf < 0) return FL_OK;
+  fl_context *ctx = det->ctx;
+  FL_HIP(ctx, hipEventRecord(det->ev_read[host_buf], ctx->stream));
+  det->read_pending[host_buf] = true;
   return FL_OK;
 }
 
@@ -75,12 +120,14 @@ extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t
 {
   const uint16_t *depth_base = nullptr;
   size_t depth_stride = 0;
-  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride);
+  int host_buf = -1;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride, &host_buf);
   if (rc) return rc;
   fl_context *ctx = det->ctx;
   FL_HIP(ctx, hipMemsetAsync(det->d_results, 0, sizeof(fl_recognition_result) * (size_t)n_frames, ctx->stream));
   rc = fl_launch_detection_batch(det, n_frames, K, params, depth_base, depth_stride);
   if (rc) return rc;
+  if ((rc = input_done(det, host_buf))) return rc;
   FL_HIP(ctx, hipEventRecord(det->ev[6], ctx->stream));
   FL_HIP(ctx, hipMemcpyAsync(det->h_results, det->d_results, sizeof(fl_recognition_result) * (size_t)n_frames,
                              hipMemcpyDeviceToHost, ctx->stream));
@@ -177,7 +224,8 @@ extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uin
   if (det && det->M != 2) return fl_set_error(det->ctx, FL_ERR_INVALID, "needs the colour + depth modalities");
   const uint16_t *depth_base = nullptr;
   size_t depth_stride = 0;
-  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride);
+  int host_buf = -1;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride, &host_buf);
   if (rc) return rc;
   fl_context *ctx = det->ctx;
   det->have_times = false;
@@ -190,6 +238,7 @@ extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uin
   fl_recognition_result *d_res = (fl_recognition_result *)((uint8_t *)sv + icp_bytes);
   FL_HIP(ctx, hipMemsetAsync(d_res, 0, res_bytes, ctx->stream));
   if ((rc = fl_launch_detection_topk(det, n_frames, k, K, params, depth_base, depth_stride, (uint8_t *)sv, d_res))) return rc;
+  if ((rc = input_done(det, host_buf))) return rc;
   FL_HIP(ctx, hipMemcpyAsync(results, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   det->last_batch = n_frames;
