@@ -212,7 +212,7 @@ def main():
               (ph[0] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6),
               file=sys.stderr)
     pcie = None
-    if args.host_frames_steps > 0:
+    if args.host_frames_steps > 0 and world == 1:          # like cpu_baseline: N = 1 only
         # informational: the same step with host frames (pinned), i.e. 1.54 MB per frame over PCIe inside the step
         h_bgr = torch.from_numpy(bgrs).pin_memory()
         h_depth = torch.from_numpy(depths.view(np.int16)).pin_memory()
