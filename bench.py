@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-frames-steps", type=int, default=2,
+    ap.add_argument("--host-frames-steps", type=int, default=6,
                     help="extra untimed-for-value steps with the frames in pinned HOST memory (upload inside the step): the "
                          "PCIe-inclusive rate reported as pcie_inclusive (0 = skip)")
     ap.add_argument("--eager-frontend", action="store_true",
