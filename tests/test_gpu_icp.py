@@ -380,3 +380,43 @@ def test_batch_topk_equals_per_frame_topk(ctx, oracle):
             assert np.array_equal(_bits(a["pose"]), _bits(b["pose"]))
             assert a["det"]["icp"]["iters"] == b["det"]["icp"]["iters"]
     det.close()
+
+
+def test_device_frames_in_place_and_gathered_equal_host_frames(ctx, oracle):
+    """fl_recognize_submit reads device frames at a regular pitch in place (what bench.py times), gathers device frames at
+    irregular addresses into the frame workspaces, and uploads host frames on its copy stream: same results all three ways."""
+    import torch
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=3, n_views=5, n_random=10)
+    fb = [sc["bgr"], sc["bgr"][:, ::-1].copy(), np.roll(sc["bgr"], 60, axis=1)]
+    fd = [sc["depth"], sc["depth"][:, ::-1].copy(), np.roll(sc["depth"], 60, axis=1)]
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480, max_batch=3)
+    params = L.RecognitionParams(75.0, 10, 0.5, 0.01, L.FL_ICP_PARITY)
+    host = det.recognize_batch(fb, fd, sc["K"], 75.0, 10, 0.5, 0.01)
+    assert host[0]["found"] == 1
+    # one device array per modality: regular pitch, read in place
+    d_b = torch.from_numpy(np.stack(fb)).cuda()
+    d_d = torch.from_numpy(np.stack(fd).view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    det.recognize_submit_device([d_b.data_ptr() + i * 640 * 480 * 3 for i in range(3)],
+                                [d_d.data_ptr() + i * 640 * 480 * 2 for i in range(3)], sc["K"], params)
+    in_place = [api.recognition_result_to_dict(r) for r in det.recognize_collect(3)]
+    # separate allocations in a different order: irregular addresses, gathered
+    tb = [torch.from_numpy(fb[i]).cuda() for i in (2, 0, 1)]
+    td = [torch.from_numpy(fd[i].view(np.int16)).cuda() for i in (1, 2, 0)]
+    torch.cuda.synchronize()
+    pb = {2: tb[0], 0: tb[1], 1: tb[2]}
+    pd = {1: td[0], 2: td[1], 0: td[2]}
+    det.recognize_submit_device([pb[i].data_ptr() for i in range(3)], [pd[i].data_ptr() for i in range(3)], sc["K"], params)
+    gathered = [api.recognition_result_to_dict(r) for r in det.recognize_collect(3)]
+    for h, a, g in zip(host, in_place, gathered):
+        for o in (a, g):
+            assert o["found"] == h["found"] and o["n_matches"] == h["n_matches"] and o["best"] == h["best"]
+            assert np.array_equal(_bits(o["pose"]), _bits(h["pose"]))
+    # back-to-back host batches alternate between the two upload buffers
+    again = det.recognize_batch(fb, fd, sc["K"], 75.0, 10, 0.5, 0.01)
+    third = det.recognize_batch(fb[::-1], fd[::-1], sc["K"], 75.0, 10, 0.5, 0.01)
+    for h, a, t in zip(host, again, third[::-1]):
+        assert np.array_equal(_bits(a["pose"]), _bits(h["pose"])) and np.array_equal(_bits(t["pose"]), _bits(h["pose"]))
+    det.close()
