@@ -136,4 +136,9 @@ class CObjRecoLmICPHip;
 int CadRecoRecognitionBatch(CObjRecoCAD *handle, int n_frames, const TImageU *rgb, const TImageU16 *depth,
                             const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out);
 
+// Opt-in, not in the reference (its Recognition() only ever looks at matches[0]): refine the first k matches of every
+// frame and return the nonMaximumSuppression (ICP/NMS.cpp:6-40, th_obj_dist = nms_dist_mm) winners, best first, in
+// vtResult.  k = 1 restores the reference behaviour.
+int CadRecoSetMultiHypothesis(CObjRecoCAD *handle, int k, float nms_dist_mm);
+
 #endif  // FEALESS_CADRECO_H

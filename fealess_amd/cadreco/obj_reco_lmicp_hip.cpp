@@ -147,12 +147,37 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
     // NB: like the reference (:190) detection() gets the caller's UN-zoomed intrinsics together with the zoomed
     // depth image (the zoomed copy only feeds SetCamIntrinsic, :236-244); identical when the input is 640 wide
     fl_intrinsics k = {w, h, K.dFx, K.dFy, K.dCx, K.dCy};
+    out.resize(n);
+    if (m_topk > 1) {
+      // opt-in extension (CadRecoSetMultiHypothesis): the first m_topk matches of every frame are refined and
+      // nonMaximumSuppression (ICP/NMS.cpp:6-40) keeps one hypothesis per object position, best first
+      std::vector<fl_recognition_result> res((size_t)n * m_topk);
+      std::vector<int> cnt(n), win(m_topk);
+      if (fl_recognize_batch_topk(m_det, n, bp.data(), dp.data(), FL_MEM_HOST, &k, &m_params, m_topk, res.data(), cnt.data()) != FL_OK) {
+        fprintf(stderr, "[fealess_hip] %s\n", fl_last_error(m_ctx));
+        return (int)ERROR_INVALID_PARAM;
+      }
+      for (int i = 0; i < n; ++i) {
+        const fl_recognition_result *r = res.data() + (size_t)i * m_topk;
+        if (cnt[i] > 0 && r[0].status != FL_OK && r[0].status != FL_ERR_ASSERT) return (int)ERROR_INVALID_PARAM;
+        int nw = 0;
+        if (fl_nms(r, cnt[i], m_nms_dist, win.data(), &nw) != FL_OK) return (int)ERROR_INVALID_PARAM;
+        for (int g = 0; g < nw; ++g) {
+          const fl_recognition_result &h = r[win[g]];
+          if (!h.found) continue;
+          TObjRecoResult o;
+          o.strObjTag = m_class_ids[h.best.class_idx];
+          memcpy(o.tWorld2Cam, h.pose, sizeof(o.tWorld2Cam));
+          out[i].push_back(o);
+        }
+      }
+      return 0;
+    }
     std::vector<fl_recognition_result> res(n);
     if (fl_recognize_batch(m_det, n, bp.data(), dp.data(), FL_MEM_HOST, &k, &m_params, res.data()) != FL_OK) {
       fprintf(stderr, "[fealess_hip] %s\n", fl_last_error(m_ctx));
       return (int)ERROR_INVALID_PARAM;
     }
-    out.resize(n);
     for (int i = 0; i < n; ++i) {
       if (res[i].status != FL_OK) return (int)ERROR_INVALID_PARAM;          // match() returned -1 / ROI assert
       if (!res[i].found) continue;                                          // vtResult stays empty, return 0 (:106-109)
@@ -165,6 +190,8 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
   }
 
   fl_recognition_params m_params;
+  int m_topk = 1;            // > 1: multi-hypothesis mode (CadRecoSetMultiHypothesis)
+  float m_nms_dist = 20.0f;  // th_obj_dist of nonMaximumSuppression, mm
 
  private:
   fl_context *m_ctx = nullptr;
@@ -202,8 +229,32 @@ int CadRecoRecognitionBatch(CObjRecoCAD *handle, int n_frames, const TImageU *rg
   return h->Batch(n_frames, rgb, depth, K, out);
 }
 
+int CadRecoSetMultiHypothesis(CObjRecoCAD *handle, int k, float nms_dist_mm)
+{
+  CObjRecoLmICPHip *h = dynamic_cast<CObjRecoLmICPHip *>(handle);
+  if (!h || k < 1 || k > 1024 || !(nms_dist_mm >= 0.f)) return (int)ERROR_INVALID_PARAM;
+  h->m_topk = k;
+  h->m_nms_dist = nms_dist_mm;
+  return 0;
+}
+
 // ---- flat C shim so that the pytest harness (ctypes) can drive the C++ facade -------------------
 extern "C" {
+int cadreco_set_multi_hypothesis(void *h, int k, float nms_dist_mm) { return CadRecoSetMultiHypothesis((CObjRecoCAD *)h, k, nms_dist_mm); }
+// Recognition() returning every result: poses16 receives min(*n_results, cap) 4x4 matrices
+int cadreco_recognition_all(void *h, const unsigned char *bgr, const unsigned short *depth, int w, int h_, double ts, int kw, int kh,
+                            double fx, double fy, double cx, double cy, int *n_results, float *poses16, int cap)
+{
+  TImageU rgb = {ts, (unsigned char *)bgr, w, h_};
+  TImageU16 dep = {ts, (unsigned short *)depth, w, h_};
+  TCamIntrinsicParam K;
+  K.nWidth = kw; K.nHeight = kh; K.dFx = fx; K.dFy = fy; K.dCx = cx; K.dCy = cy;
+  vector<TObjRecoResult> out;
+  const int rc = ((CObjRecoCAD *)h)->Recognition(rgb, dep, K, out);
+  *n_results = (int)out.size();
+  for (int i = 0; i < (int)out.size() && i < cap; ++i) memcpy(poses16 + 16 * i, out[i].tWorld2Cam, 16 * sizeof(float));
+  return rc;
+}
 void *cadreco_create(int type) { return CObjRecoCAD::Create((CObjRecoCAD::EObjRecoType)type); }
 void cadreco_destroy(void *h) { CObjRecoCAD::Destroy((CObjRecoCAD *)h); }
 int cadreco_add_obj(void *h, const char *dir) { return ((CObjRecoCAD *)h)->AddObj(dir); }

@@ -110,6 +110,24 @@ def test_cadreco_facade_end_to_end(tmp_path, oracle):
     exp2 = oracle.recognition(bgr, depth, (2 * fx, 2 * fy, 2 * cx, 2 * cy), [5, 8], sc["bank"], 75.0, 10, 0.5, 0.01)
     assert np.abs(pose.reshape(4, 4) - exp2["pose"]).max() <= 1e-4
     assert reco() == 0 and np.abs(pose.reshape(4, 4) - exp["pose"]).max() <= 1e-4      # back to 640x480 (re-finalize not needed)
+    # opt-in multi-hypothesis mode (CadRecoSetMultiHypothesis): the first k matches refined, NMS winners returned, best first
+    lib.cadreco_set_multi_hypothesis.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    assert lib.cadreco_set_multi_hypothesis(h, 0, 20.0) == C.c_int(0x80000001).value
+    assert lib.cadreco_set_multi_hypothesis(h, 6, 20.0) == 0
+    lib.cadreco_set_params.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int]
+    assert lib.cadreco_set_params(h, 60.0, 8, 0.3, 0.01, 0) == 0
+    poses = np.zeros((8, 16), np.float32)
+    rc = lib.cadreco_recognition_all(h, bgr.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p), 640, 480, C.c_double(1.0),
+                                     640, 480, C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy), C.byref(n),
+                                     poses.ctypes.data_as(C.c_void_p), 8)
+    hyp, win = oracle.recognition_topk(bgr, depth, sc["K"], [5, 8], sc["bank"], 6, 60.0, 8, 0.3, 0.01, nms_dist=20.0)
+    want = [hyp[i]["pose"] for i in win if hyp[i]["found"]]
+    assert rc == 0 and n.value == len(want) >= 1
+    for i, wp in enumerate(want):
+        assert np.abs(poses[i].reshape(4, 4) - wp).max() <= 1e-4
+    assert lib.cadreco_set_multi_hypothesis(h, 1, 20.0) == 0              # back to the reference behaviour: matches[0] only
+    assert lib.cadreco_set_params(h, 75.0, 10, 0.5, 0.01, 0) == 0
+    assert reco() == 0 and n.value == 1 and np.abs(pose.reshape(4, 4) - exp["pose"]).max() <= 1e-4
     lib.cadreco_destroy(h)
 
 
