@@ -131,7 +131,6 @@ struct IcpShared {
   double dsum[ICP_BS / 64][32];   // [wave][scalar]
   int iscan[ICP_BS / 64 + 1];
   int iscan2[2][ICP_BS / 64];          // crop_clouds: per-wave kept counts, double-buffered
-  int ibase;
   float fred[4][ICP_BS / 64];
   int n, rect_m[4], rect_r[4], status, g;
   // double-buffered LDS tiles feeding the sequential float32 chains (FL_ICP_PARITY):
@@ -147,28 +146,6 @@ struct IcpShared {
 __device__ __forceinline__ bool vvalid(float z) { return z <= 900.0f; }      // common.cpp:261-266
 
 // ---- block-level helpers (every thread of the workgroup must call) ---------------------------
-__device__ __forceinline__ int block_excl_scan(IcpShared &S, int v, int *total)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int t = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += t;
-  }
-  __syncthreads();
-  if (lane == 63) S.iscan[wave] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int i = 0; i < nw; ++i) { int t = S.iscan[i]; S.iscan[i] = run; run += t; }
-    S.iscan[nw] = run;
-  }
-  __syncthreads();
-  *total = S.iscan[nw];
-  return S.iscan[wave] + inc - v;
-}
-
 __device__ __forceinline__ int block_sum_int(IcpShared &S, int v)
 {
 #pragma unroll
@@ -328,37 +305,6 @@ __device__ __forceinline__ bool finite_all(const float *v, int n)
 }
 
 // ---- sequential float32 chains (FL_ICP_PARITY) ------------------------------------------------
-// lane k < width accumulates column k of a row-major [n][stride] float table, in row order.
-__device__ __forceinline__ float chain_sum(const float *tab, int n, int stride, int k, bool active)
-{
-  float acc = 0.0f;
-  if (active) {
-    // one memory round trip per 16 elements would be the whole cost: the next batch is in flight while this one is added
-    const float *p = tab + k;
-    int i = 0;
-    float v[16], w[16];
-    if (n >= 16) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = p[(size_t)u * stride];
-    }
-    for (; i + 32 <= n; i += 16) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) w[u] = p[(size_t)(i + 16 + u) * stride];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc += v[u];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = w[u];
-    }
-    if (i + 16 <= n) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc += v[u];
-      i += 16;
-    }
-    for (; i < n; ++i) acc += p[(size_t)i * stride];
-  }
-  return acc;
-}
-
 // one chain step over an LDS tile: acc += col[0], col[1], ... col[rows-1], strictly in order.
 // The adds are one dependent chain; what made a tile slow was the LDS read latency in front of every 16 of
 // them.  The column (16-byte aligned) is read 16 rows at a time with four ds_read_b128, two batches in flight:
