@@ -306,7 +306,7 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *p)
 }
 
 #ifndef FL_SCAN_WPE
-#define FL_SCAN_WPE 4             // measured: 5 or 6 waves per SIMD spill and are 25-55 % slower
+#define FL_SCAN_WPE 5             // waves per SIMD; measured after the DPP change (ms per 1280 frames x 360 templates): 3: 2.32, 4: 1.95, 5: 1.71, 6: 1.77, 8: 2.17
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE, FL_SCAN_WPE))) void k_scan(ScanArgs a)
 {
