@@ -444,6 +444,10 @@ struct RefineArgs {
   float threshold;
 };
 
+#ifndef FL_REFINE_WPE
+#define FL_REFINE_WPE 6           // waves per SIMD; measured (ms per 1280 frames): 4: 0.92, 5 (the compiler's choice): 0.80, 6: 0.76, 8: 1.03
+#endif
+__attribute__((amdgpu_waves_per_eu(FL_REFINE_WPE, FL_REFINE_WPE)))
 __global__ __launch_bounds__(256) void k_refine(RefineArgs a)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
