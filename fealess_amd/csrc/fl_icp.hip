@@ -28,6 +28,7 @@
 #include <float.h>
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 
 #ifndef FL_ICP_BS
 #define FL_ICP_BS 256
@@ -47,7 +48,7 @@
 #define FL_ICP_FAST_WPE 1          // minimum waves per SIMD the FL_ICP_FAST kernel is compiled for
 #endif
 #ifndef FL_ICP_PLANE_WPE
-#define FL_ICP_PLANE_WPE 3         // minimum waves per SIMD the point-to-plane kernel is compiled for (168 VGPRs; measured 1: 45.5, 3: 41.8, 4: 43.0 ms)
+#define FL_ICP_PLANE_WPE 5         // waves per SIMD the point-to-plane kernel is compiled for (96 VGPRs, 5 workgroups per CU; ICP ms per 1280 frames: 3: 41.0, 4: 37.3, 5: 36.3)
 #endif
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
@@ -780,7 +781,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     constexpr int mode = MODE;
     int kept = 0;
     const bool index_pairs = iter == 1 && !plane;       // :700-704
-    double ds[NSUM];
+    // fast: fp64 per-thread partials.  point-to-plane: the thread's ~60 terms are summed in float32 (27 registers
+    // instead of 54 -- what lets the kernel run 5 workgroups per CU like the parity one) and only the cross-thread tree
+    // runs in fp64; the 6x6 system is re-linearised every iteration, so a 1e-6 relative error in a sum is immaterial.
+    typename std::conditional<plane, float, double>::type ds[NSUM];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) ds[k] = 0.0;
     if (!index_pairs) {
@@ -809,9 +813,9 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           // linearised point-to-plane: residual e = n.(m - r), Jacobian row J = [m x n, n] wrt (omega, t);
           // ds = upper triangle of sum J J^T (21) followed by sum J e (6)
           const F3 rv = ld3_u32(ref, j), nv = ld3_u32(nrm, j);
-          const double n0 = nv.x, n1 = nv.y, n2 = nv.z, m0 = qx, m1 = qy, m2 = qz;
-          const double J[6] = {m1 * n2 - m2 * n1, m2 * n0 - m0 * n2, m0 * n1 - m1 * n0, n0, n1, n2};
-          const double e = n0 * (m0 - (double)rv.x) + n1 * (m1 - (double)rv.y) + n2 * (m2 - (double)rv.z);
+          const float n0 = nv.x, n1 = nv.y, n2 = nv.z, m0 = qx, m1 = qy, m2 = qz;
+          const float J[6] = {m1 * n2 - m2 * n1, m2 * n0 - m0 * n2, m0 * n1 - m1 * n0, n0, n1, n2};
+          const float e = n0 * (m0 - rv.x) + n1 * (m1 - rv.y) + n2 * (m2 - rv.z);
           int q = 0;
 #pragma unroll
           for (int a = 0; a < 6; ++a)
@@ -946,7 +950,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
       if (threadIdx.x < 15) S.sums[threadIdx.x] = acc;
       __syncthreads();
     } else {
-      block_sum_double<NSUM>(S, ds);
+      double dd[NSUM];
+#pragma unroll
+      for (int k = 0; k < NSUM; ++k) dd[k] = (double)ds[k];
+      block_sum_double<NSUM>(S, dd);
     }
     if (plane) {
       if (threadIdx.x == 0) {
@@ -1157,7 +1164,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE), MODE == FL_ICP_PARITY ? FL_ICP_WPE : 4))) void k_icp_pipeline(IcpArgs a)
+__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE), MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE && FL_ICP_PLANE_WPE > 4 ? FL_ICP_PLANE_WPE : 4)))) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;
