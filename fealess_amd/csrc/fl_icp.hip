@@ -15,7 +15,7 @@
 //   * FL_ICP_PARITY: each of the 15 centroid/covariance scalars (and the distance sum) is a
 //     float32 chain accumulated in the reference's order by its own lane; dropped pairs add an
 //     exact +0.0f so the chain is branch-free.  Bit-identical to the reference's arithmetic.
-//   * FL_ICP_FAST: fp64 per-thread partials + fixed-shape tree, rounded once to float32.
+//   * FL_ICP_FAST: per-thread partials + fixed-shape fp64 tree, rounded once to float32.
 //   * FL_ICP_POINT_TO_PLANE (no reference counterpart): NN pairs from the first
 //     iteration on, 27 fp64 sums of the linearised point-to-plane system, 6x6 Cholesky + Rodrigues.
 // Nearest neighbours: the reference's FLANN kd-tree (exact 1-NN, eps 0) is replaced by a uniform
@@ -44,12 +44,18 @@
 #define FL_ICP_WPE 5               // waves per SIMD the recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96):
                                   // measured +4 % frames/s at 5 workgroups per CU (LDS: 5 x 27 KB)
 #endif
+#ifndef FL_ICP_FAST_F32
+#define FL_ICP_FAST_F32 1          // FL_ICP_FAST keeps its per-thread partial sums (~60 terms) in float32, like the point-to-plane mode;
+                                  // the cross-thread tree is fp64.  0: fp64 partials (161 VGPRs, 3 workgroups per CU: 18.6 ms per 1280 frames)
+#endif
 #ifndef FL_ICP_FAST_WPE
-#define FL_ICP_FAST_WPE 1          // minimum waves per SIMD the FL_ICP_FAST kernel is compiled for
+#define FL_ICP_FAST_WPE 5          // waves per SIMD the FL_ICP_FAST kernel is compiled for (96 VGPRs with float32 partials: 15.8 ms per 1280 frames)
 #endif
 #ifndef FL_ICP_PLANE_WPE
 #define FL_ICP_PLANE_WPE 5         // waves per SIMD the point-to-plane kernel is compiled for (96 VGPRs, 5 workgroups per CU; ICP ms per 1280 frames: 3: 41.0, 4: 37.3, 5: 36.3)
 #endif
+// waves per SIMD kernel k_icp_pipeline<MODE> is compiled for (minimum; the maximum is 4 unless more is asked for)
+#define ICP_MODE_WPE(MODE) ((MODE) == FL_ICP_PARITY ? FL_ICP_WPE : ((MODE) == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE))
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
@@ -784,7 +790,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     // fast: fp64 per-thread partials.  point-to-plane: the thread's ~60 terms are summed in float32 (27 registers
     // instead of 54 -- what lets the kernel run 5 workgroups per CU like the parity one) and only the cross-thread tree
     // runs in fp64; the 6x6 system is re-linearised every iteration, so a 1e-6 relative error in a sum is immaterial.
-    typename std::conditional<plane, float, double>::type ds[NSUM];
+    typename std::conditional<plane || FL_ICP_FAST_F32 != 0, float, double>::type ds[NSUM];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) ds[k] = 0.0;
     if (!index_pairs) {
@@ -1164,7 +1170,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE), MODE == FL_ICP_PARITY ? FL_ICP_WPE : (MODE == FL_ICP_POINT_TO_PLANE && FL_ICP_PLANE_WPE > 4 ? FL_ICP_PLANE_WPE : 4)))) void k_icp_pipeline(IcpArgs a)
+__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(ICP_MODE_WPE(MODE), ICP_MODE_WPE(MODE) > 4 ? ICP_MODE_WPE(MODE) : (MODE == FL_ICP_PARITY ? FL_ICP_WPE : 4)))) void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
   IcpShared &S = *(IcpShared *)icp_smem;

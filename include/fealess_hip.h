@@ -47,11 +47,11 @@ typedef enum { FL_MEM_HOST = 0, FL_MEM_DEVICE = 1 } fl_mem;
  *                   sequential float32 chains in the reference's order (one lane per scalar),
  *                   so results are bit-identical to the reference's arithmetic (ICP.cpp:8-25,
  *                   731-735, 68-111).  Default.
- *   FL_ICP_FAST   : the same sums as parallel fp64 tree reductions rounded once to float32
- *                   (more accurate than the reference, not bit-identical to it).  Despite the
- *                   name it is not the quicker one on MI355X any more: the nearest-neighbour
- *                   search dominates both, and the parity kernel runs 5 workgroups per CU
- *                   (17.2 vs 18.6 ms per 1280 frames).
+ *   FL_ICP_FAST   : the same sums as parallel reductions (float32 per-thread partials of ~60
+ *                   terms, fp64 tree across the workgroup, rounded once to float32): closer to the
+ *                   exact sums than the reference's float32 chains, not bit-identical to them.
+ *                   About 6 % quicker than FL_ICP_PARITY (15.8 vs 16.8 ms per 1280 frames): the
+ *                   exact nearest-neighbour search dominates both.
  *   FL_ICP_POINT_TO_PLANE : opt-in extension with NO counterpart in the reference (SURVEY.md
  *                   section 8f rank 4): every iteration (the first included) pairs each model point
  *                   with its exact nearest reference point, gates the pair at distance
