@@ -208,9 +208,13 @@ def main():
         el = float(tmax.item())
     if os.environ.get("FL_ICP_PHASES"):   # dev aid (tools/dev): a library built with -DFL_ICP_PHASES returns phase cycles in R
         ph = np.array([[r.det.icp.R[k] for k in range(8)] for r in res]).mean(0)
-        print("icp phase Mcycles mean: grid %.2f A1 %.2f A2 %.2f svd %.2f B %.2f | before icp_run %.2f, whole kernel %.2f" %
-              (ph[0] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6),
+        print("icp phase Mcycles mean: grid %.2f A1check %.2f A1search %.2f A2 %.2f svd %.2f B %.2f | before icp_run %.2f, whole kernel %.2f" %
+              (ph[0] / 1e6, ph[1] / 1e6, ph[2] / 1e6, ph[3] / 1e6, ph[4] / 1e6, ph[5] / 1e6, ph[6] / 1e6, ph[7] / 1e6),
               file=sys.stderr)
+        st = np.array([[r.det.icp.R[8], r.det.icp.T[0], r.det.icp.T[1], r.det.icp.T[2], r.det.icp.dist_mean] for r in res]).mean(0)
+        print("icp organised search per frame: steps %.0f, positions per step %.1f (iterations 1-3: %.0f%% of all), fallback steps %.1f%%, "
+              "staged points per step %.0f" % (st[0], st[1] / max(st[0], 1), 100 * st[4] / max(st[1], 1), 100 * st[2] / max(st[0], 1),
+                                                st[3] / max(st[0], 1)), file=sys.stderr)
     pcie = None
     if args.host_frames_steps > 0 and world == 1:          # like cpu_baseline: N = 1 only
         # informational: the same step with host frames (pinned), i.e. 1.54 MB per frame over PCIe inside the step

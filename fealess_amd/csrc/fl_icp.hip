@@ -18,11 +18,25 @@
 //   * FL_ICP_FAST: per-thread partials + fixed-shape fp64 tree, rounded once to float32.
 //   * FL_ICP_POINT_TO_PLANE (no reference counterpart): NN pairs from the first
 //     iteration on, 27 fp64 sums of the linearised point-to-plane system, 6x6 Cholesky + Rodrigues.
+// The workgroup is 256 threads at full batches (5 workgroups per CU) and 1024 threads when the batch
+// would leave CUs idle anyway (a camera-rate caller: 1-8 frames): the search and the chain producers get
+// 4x the lanes and a frame's latency drops to about what its sequential chains cost.
+//
 // Nearest neighbours: the reference's FLANN kd-tree (exact 1-NN, eps 0) is replaced by a uniform
 // x/y cell grid over the static reference cloud built once per frame; a query only visits the
 // cells within sqrt(3*dist_mean) because farther neighbours are discarded anyway
 // (PointsCorresponding keeps d^2 <= 3*dist_mean, ICP.cpp:268,708).  Distances use L2_Simple's
 // float expression ((dx*dx + dy*dy) + dz*dz); ties go to the lowest index.
+//
+// Organised search (the recognition / detection() pipeline, where both clouds are back-projected crops).  The grid, its
+// CSR headers and their gathers are not needed there: the reference cloud is kept as an IMAGE (refimg: crop pixel ->
+// point + index, a point at infinity where the pixel was dropped), and the reference points within distance r of a query
+// q can only come from the pixels its ball projects to -- u in [fx (qx -+ r) / (qz +- r)], likewise v -- a window of a
+// few pixels.  Queries are taken in 8x8-pixel tile order (a permutation built once per frame), so the 64 queries of a
+// wave share a compact union window; the wave stages that window into its share of the (idle) chain tiles in LDS with a
+// handful of coalesced loads and every lane enumerates its own window from LDS.  When the union does not fit (the first
+// iterations, where sqrt(3 dist_mean) is several pixels) the same enumeration reads the image from L2 instead.
+// fl_icp() (caller-supplied clouds, no image structure) keeps the grid search.
 // Built with -ffp-contract=off: one IEEE binary32/64 operation per operator.
 #include "fl_internal.h"
 #include <float.h>
@@ -30,49 +44,45 @@
 #include <string.h>
 #include <type_traits>
 
-#ifndef FL_ICP_BS
-#define FL_ICP_BS 256
-#endif
-#define ICP_BS FL_ICP_BS         // threads per frame workgroup (64 chain lanes + ICP_BS - 64 producers in parity mode)
+#define ICP_BS_SMALL 256
+#define ICP_BS_WIDE 1024
 #ifdef FL_ICP_PHASES
 #define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
 #else
 #define TSTAMP(k) do { } while (0)
 #endif
-#define ICP_MAX_THREADS ICP_BS
 #ifndef FL_ICP_WPE
-#define FL_ICP_WPE 5               // waves per SIMD the recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96):
-                                  // measured +4 % frames/s at 5 workgroups per CU (LDS: 5 x 27 KB)
+#define FL_ICP_WPE 5               // waves per SIMD the 256-thread recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96)
 #endif
 #ifndef FL_ICP_FAST_F32
 #define FL_ICP_FAST_F32 1          // FL_ICP_FAST keeps its per-thread partial sums (~60 terms) in float32, like the point-to-plane mode;
-                                  // the cross-thread tree is fp64.  0: fp64 partials (161 VGPRs, 3 workgroups per CU: 18.6 ms per 1280 frames)
+                                  // the cross-thread tree is fp64.  0: fp64 partials
 #endif
 #ifndef FL_ICP_FAST_WPE
-#define FL_ICP_FAST_WPE 5          // waves per SIMD the FL_ICP_FAST kernel is compiled for (96 VGPRs with float32 partials: 15.8 ms per 1280 frames)
+#define FL_ICP_FAST_WPE 5
 #endif
 #ifndef FL_ICP_PLANE_WPE
-#define FL_ICP_PLANE_WPE 5         // waves per SIMD the point-to-plane kernel is compiled for (96 VGPRs, 5 workgroups per CU; ICP ms per 1280 frames: 3: 41.0, 4: 37.3, 5: 36.3)
+#define FL_ICP_PLANE_WPE 4
 #endif
-// waves per SIMD kernel k_icp_pipeline<MODE> is compiled for (minimum; the maximum is 4 unless more is asked for)
+// waves per SIMD kernel k_icp_pipeline<MODE, 256> is compiled for
 #define ICP_MODE_WPE(MODE) ((MODE) == FL_ICP_PARITY ? FL_ICP_WPE : ((MODE) == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE))
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
-#define ICP_TQ (ICP_BS - 64)        // rows per LDS tile: virtual wave 0 chains, the other three produce one row per thread
-#define ICP_TS (ICP_TQ + 4)         // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4 keeps
-                                  // the 16 chain lanes of a b128 read on distinct bank groups
 
 // HBM layout of one frame's ICP workspace (n = capacity in points):
 //   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
 //   mod   n x 3 f32   model cloud, transformed in place every iteration
-//   sref  n x float4  reference cloud sorted by grid cell, w = original index (bit pattern)
+//   sref  (n+1) x float4   grid search: reference cloud sorted by grid cell, w = original index (bit pattern);
+//                     organised search: the reference IMAGE, crop pixel p -> (point, index) or a point at infinity
+//                     with index NN_IDX_NONE where the pixel was dropped by the paired compaction
 //   nn     n x i32    nearest reference index j of model point i (kept pair: j, dropped: -1)
 //   bnd    n x f32    upper bound on the distance from model point i to its nearest reference point
-//   cell_start / cell_cur   CSR offsets of the x/y cell grid
+//   perm   n x i32    organised search: model indices in 8x8-pixel tile order
+//   cell_start / cell_cur   CSR offsets of the x/y cell grid (grid search)
 //   nrm   n x 3 f32   unit normals of the reference cloud, index order (FL_ICP_POINT_TO_PLANE only; 0 = unknown)
 struct IcpWsLayout {
-  size_t ref, mod, sref, nn, bnd, cell_start, cell_cur, nrm, total;
+  size_t ref, mod, sref, nn, bnd, perm, cell_start, cell_cur, nrm, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -83,9 +93,10 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.ncell_max = n + 4096;
   L.ref = o; o = al256(o + 12 * nn);
   L.mod = o; o = al256(o + 12 * nn);
-  L.sref = o; o = al256(o + 16 * nn);
+  L.sref = o; o = al256(o + 16 * (nn + 1));
   L.nn = o; o = al256(o + 4 * nn);
   L.bnd = o; o = al256(o + 4 * nn);
+  L.perm = o; o = al256(o + 4 * nn);
   L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
   L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
   L.nrm = o; o = al256(o + 12 * nn);
@@ -128,23 +139,42 @@ struct IcpArgs {
   fl_recognition_result *results;
 };
 
-struct IcpShared {
+// LDS state of one frame workgroup of BS_ threads.  Parity mode: virtual wave 0 chains, the other BS/64 - 1 waves
+// produce one tile row per thread.
+template <int BS_>
+struct IcpSharedT {
+  static constexpr int BS = BS_;
+  static constexpr int NW = BS_ / 64;
+  // Parity mode: wave 0 runs the chains, producer waves write one tile row per thread.  A 16-wave workgroup keeps the
+  // waves that share wave 0's SIMD (waves 4, 8, 12: the SPI deals a workgroup's waves round-robin over the 4 SIMDs) out
+  // of the producer role, so the chain wave has its SIMD's issue slots to itself.
+  static constexpr int NPROD = NW >= 8 ? NW - NW / 4 : NW - 1;
+  static constexpr int CHAIN_NBUF = BS_ >= 1024 ? 4 : 2;
+  static constexpr int TQ = NPROD * 64;   // rows per LDS tile
+  // tile row of this thread, or -1 (chain wave / idle wave)
+  static __device__ __forceinline__ int producer_slot()
+  {
+    const int t = (int)threadIdx.x, w = t >> 6;
+    if (NW >= 8) return (w & 3) == 0 ? -1 : t - 64 * (1 + (w >> 2));
+    return t - 64;
+  }
+  static constexpr int TS = TQ + 4;       // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4
+                                          // keeps the 16 chain lanes of a b128 read on distinct bank groups
   float R[9], T[3], Ropt[9], Topt[3];
   float dist_mean, dist_diff, px, thr;
   int iter, n_corr, go, ok;
   float xmin, ymin, inv_c;
   int GX, GY, nsorted;
   float sums[16];
-  double dsum[ICP_BS / 64][32];   // [wave][scalar]
-  int iscan[ICP_BS / 64 + 1];
-  int iscan2[2][ICP_BS / 64];          // crop_clouds: per-wave kept counts, double-buffered
-  float fred[4][ICP_BS / 64];
+  double dsum[NW][32];                  // [wave][scalar]
+  int iscan[NW + 1];
+  int iscan2[2][NW];                    // crop_clouds / CSR scan: per-wave counts, double-buffered
+  float fred[4][NW];
   int n, rect_m[4], rect_r[4], status, g;
   // double-buffered LDS tiles feeding the sequential float32 chains (FL_ICP_PARITY):
-  // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords, pad) of row r of tile b;
-  // +1 column of padding puts the 16 chain lanes on 16 different banks
-  alignas(16) float prod[2][15][ICP_TS];
-  alignas(16) float dtile[2][ICP_TQ];
+  // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords) of row r of tile b
+  alignas(16) float prod[2][15][TS];
+  alignas(16) float dtile[2][TQ];
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
 #endif
@@ -153,7 +183,8 @@ struct IcpShared {
 __device__ __forceinline__ bool vvalid(float z) { return z <= 900.0f; }      // common.cpp:261-266
 
 // ---- block-level helpers (every thread of the workgroup must call) ---------------------------
-__device__ __forceinline__ int block_sum_int(IcpShared &S, int v)
+template <class SH>
+__device__ __forceinline__ int block_sum_int(SH &S, int v)
 {
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
@@ -161,7 +192,8 @@ __device__ __forceinline__ int block_sum_int(IcpShared &S, int v)
   if ((threadIdx.x & 63) == 0) S.iscan[threadIdx.x >> 6] = v;
   __syncthreads();
   int t = 0;
-  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += S.iscan[i];
+#pragma unroll
+  for (int i = 0; i < SH::NW; ++i) t += S.iscan[i];
   return t;
 }
 
@@ -173,12 +205,11 @@ __device__ __forceinline__ double shfl_xor_d(double v, int s)
   return __hiloint2double(hi, lo);
 }
 
-// fixed-shape fp64 reduction of NS scalars per thread -> S.sums[k] as float is NOT done here: the
-// caller rounds.  Result (double) valid in thread 0..NS-1's return slot via S.dsum[0][k].
-template <int NS>
-__device__ __forceinline__ void block_sum_double(IcpShared &S, double *v)
+// fixed-shape fp64 reduction of NS scalars per thread; the result (double) is left in S.dsum[0][k], the caller rounds
+template <int NS, class SH>
+__device__ __forceinline__ void block_sum_double(SH &S, double *v)
 {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     double x = v[k];
@@ -192,7 +223,7 @@ __device__ __forceinline__ void block_sum_double(IcpShared &S, double *v)
   __syncthreads();
   if (threadIdx.x < NS) {
     double t = 0;
-    for (int i = 0; i < nw; ++i) t += S.dsum[i][threadIdx.x];
+    for (int i = 0; i < SH::NW; ++i) t += S.dsum[i][threadIdx.x];
     S.dsum[0][threadIdx.x] = t;
   }
   __syncthreads();
@@ -327,30 +358,35 @@ __device__ __forceinline__ float chain_add16(const float4 (&v)[4], float acc)
   for (int u = 0; u < 4; ++u) { acc += v[u].x; acc += v[u].y; acc += v[u].z; acc += v[u].w; }
   return acc;
 }
+// NBUF 16-row batches of the chain's column are kept in registers: NBUF - 1 of them are in flight while one is added (an
+// LDS read takes longer than the 16 dependent adds of a batch).  Measured: 4 in the 1024-thread kernel (128 VGPRs:
+// 9.5 -> 8.7 M cycles per frame at batch 1), 2 in the 256-thread one (96 VGPRs: 4 spills, 18 -> 21 ms per 1280 frames).
+template <int NBUF>
 __device__ __forceinline__ float chain_tile(const float *col, int rows, float acc)
 {
-  int r = 0;
-  if (rows >= 16) {
-    float4 a[4], b[4];
-    chain_load16(col, a);
-    for (; r + 48 <= rows; r += 32) {
-      chain_load16(col + r + 16, b);
-      acc = chain_add16(a, acc);
-      chain_load16(col + r + 32, a);
-      acc = chain_add16(b, acc);
+  const int nb = rows >> 4;                              // full batches
+  int b = 0;
+  if (nb >= NBUF) {
+    float4 buf[NBUF][4];
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) chain_load16(col + 16 * u, buf[u]);
+    for (; b + 2 * NBUF <= nb; b += NBUF) {              // steady state: every batch added is replaced by the one NBUF ahead
+#pragma unroll
+      for (int u = 0; u < NBUF; ++u) {
+        acc = chain_add16(buf[u], acc);
+        chain_load16(col + 16 * (b + NBUF + u), buf[u]);
+      }
     }
-    // here: batch at r is loaded in a; 16 <= rows - r < 48
-    if (r + 32 <= rows) {
-      chain_load16(col + r + 16, b);
-      acc = chain_add16(a, acc);
-      acc = chain_add16(b, acc);
-      r += 32;
-    } else {
-      acc = chain_add16(a, acc);
-      r += 16;
-    }
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) acc = chain_add16(buf[u], acc);
+    b += NBUF;
   }
-  for (; r < rows; ++r) acc += col[r];
+  for (; b < nb; ++b) {                                  // fewer than NBUF batches are left (last tile only)
+    float4 one[4];
+    chain_load16(col + 16 * b, one);
+    acc = chain_add16(one, acc);
+  }
+  for (int r = nb << 4; r < rows; ++r) acc += col[r];
   return acc;
 }
 
@@ -377,6 +413,8 @@ __device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
 // only widens the visited area; the nearest neighbour found is the same.
 __device__ __forceinline__ float sqrt_upper(float x) { return __builtin_amdgcn_sqrtf(x) * 1.000001f + 1.1e-19f; }
 
+#define NN_IDX_NONE 0x7fffffff      // index stored with a dropped pixel of the reference image (real indices are below it)
+
 // ---- uniform x/y grid over the reference cloud --------------------------------------------------
 __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
 {
@@ -385,12 +423,14 @@ __device__ __forceinline__ int cell_of(float v, float vmin, float inv_c, int G)
   return c;
 }
 
-__device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n_ref, float4 *sref, int *cell_start, int *cell_cur,
+template <class SH>
+__device__ __forceinline__ void build_grid(SH &S, const float *ref, int n_ref, float4 *sref, int *cell_start, int *cell_cur,
                            int ncell_max)
 {
+  constexpr int BS = SH::BS, NW = SH::NW;
   // bounding box of the finite points
   float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-  for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n_ref; i += BS) {
     const F3 p3 = ld3_u32(ref, i);
     const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
@@ -417,7 +457,7 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
+    for (int i = 1; i < NW; ++i) {
       xmin = fminf(xmin, S.fred[0][i]);
       xmax = fmaxf(xmax, S.fred[1][i]);
       ymin = fminf(ymin, S.fred[2][i]);
@@ -445,9 +485,9 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   }
   __syncthreads();
   const int ncell = S.GX * S.GY;
-  for (int i = threadIdx.x; i < ncell; i += blockDim.x) cell_cur[i] = 0;
+  for (int i = threadIdx.x; i < ncell; i += BS) cell_cur[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n_ref; i += BS) {
     const F3 p3 = ld3_u32(ref, i);
     const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z))
@@ -455,11 +495,11 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   }
   __syncthreads();
   // exclusive scan of the counts -> cell_start (and cell_cur, the scatter cursors): four consecutive cells per thread,
-  // a shuffle scan inside the wave, the wave totals through a double-buffered LDS slot -- one barrier per 1024 cells
+  // a shuffle scan inside the wave, the wave totals through a double-buffered LDS slot -- one barrier per 4*BS cells
   {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int run = 0, step = 0;
-    for (int base = 0; base < ncell; base += 4 * blockDim.x, ++step) {
+    for (int base = 0; base < ncell; base += 4 * BS, ++step) {
       const int i0 = base + 4 * threadIdx.x;
       int c[4];
 #pragma unroll
@@ -475,7 +515,8 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
       if (lane == 63) slot[wv] = inc;
       __syncthreads();
       int before = 0, total = 0;
-      for (int w = 0; w < nwv; ++w) { const int t = slot[w]; before += w < wv ? t : 0; total += t; }
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const int t = slot[w]; before += w < wv ? t : 0; total += t; }
       int ex = run + before + inc - mine;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -487,7 +528,7 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
     if (threadIdx.x == 0) { cell_start[ncell] = run; S.nsorted = run; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n_ref; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n_ref; i += BS) {
     const F3 p3 = ld3_u32(ref, i);
     const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
@@ -498,18 +539,15 @@ __device__ __forceinline__ void build_grid(IcpShared &S, const float *ref, int n
   __syncthreads();
 }
 
-// ---- exact 1-NN within squared distance thr (float compare as the reference's `dists <= dist_thr`)
-// cell ranges a query has to visit; false if the query cannot have a neighbour at all.
-// `bnd` is an upper bound on the distance to SOME reference point (last iteration's partner plus how far the
-// query moved since, see l2dist_phase): it only shrinks the visited area -- every point within that distance
-// is still seen, so the result is the exact nearest neighbour.  r_thr = sqrtf(thr).
+// ---- exact nearest neighbours within a window -------------------------------------------------------
 // the grid parameters as wave-uniform scalars (SGPRs): read from LDS they would each cost a VGPR in the search loop
 struct NnGrid {
   float xmin, ymin, inv_c;
   int GX, GY, nsorted;
 };
 __device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-__device__ __forceinline__ NnGrid nn_grid(const IcpShared &S)
+template <class SH>
+__device__ __forceinline__ NnGrid nn_grid(const SH &S)
 {
   NnGrid g;
   g.xmin = uniform_f(S.xmin);
@@ -521,72 +559,58 @@ __device__ __forceinline__ NnGrid nn_grid(const IcpShared &S)
   return g;
 }
 
-__device__ __forceinline__ bool nn_ranges(const NnGrid &S, float qx, float qy, float qz, float thr, float r_thr, float bnd,
-                                          int *cx0, int *cx1, int *cy0, int *cy1)
+// the radius every reference point within distance `lim` of the query lies within, inflated past the float rounding of
+// d2, of the coordinate differences and of the bound's own arithmetic (orders of magnitude below the relative margins)
+__device__ __forceinline__ float nn_radius(float qx, float qy, float qz, float lim)
 {
-  if (!(thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
-  const float lim = fminf(bnd, r_thr);                   // NaN bnd -> r_thr
-  // conservative radius: float rounding of d2, of the coordinate differences and of the bound's own
-  // arithmetic is orders of magnitude below the relative margins
-  const float r = lim * 1.0001f + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) + 1e-30f;
-  *cx0 = 0; *cx1 = S.GX - 1; *cy0 = 0; *cy1 = S.GY - 1;
-  if (isfinite(r)) {
-    *cx0 = cell_of(qx - r, S.xmin, S.inv_c, S.GX);
-    *cx1 = cell_of(qx + r, S.xmin, S.inv_c, S.GX);
-    *cy0 = cell_of(qy - r, S.ymin, S.inv_c, S.GY);
-    *cy1 = cell_of(qy + r, S.ymin, S.inv_c, S.GY);
-  }
-  return true;
+  return lim * 1.0001f + 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz)) + 1e-30f;
 }
 
-// Branch-free running minimum: (d2, index) packed as d2's bit pattern (non-negative floats order
-// like unsigned integers) in the high word and the reference index in the low word, so one
-// 64-bit unsigned min implements "smaller distance, ties to the lower index" exactly.
-#define NN_CONSIDER(P)                                                                            \
-  {                                                                                               \
-    const float dx = qx - (P).x, dy = qy - (P).y, dz = qz - (P).z;                                \
-    float d = dx * dx; /* cvflann::L2_Simple<float> */                                            \
-    d += dy * dy;                                                                                 \
-    d += dz * dz;                                                                                 \
-    const unsigned long long key_ =                                                               \
-        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int((P).w);         \
-    best = key_ < best ? key_ : best;                                                             \
-  }
-#define NN_CONSIDER_IF(P, PRED)                                                                   \
-  {                                                                                               \
-    const float dx = qx - (P).x, dy = qy - (P).y, dz = qz - (P).z;                                \
-    float d = dx * dx;                                                                            \
-    d += dy * dy;                                                                                 \
-    d += dz * dz;                                                                                 \
-    const unsigned long long key_ =                                                               \
-        ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int((P).w);         \
-    best = ((PRED) && key_ < best) ? key_ : best;                                                 \
-  }
+// (d2, index) packed as d2's bit pattern (non-negative floats order like unsigned integers) in the high word and the
+// reference index in the low word: one 64-bit unsigned minimum implements "smaller distance, ties to the lower
+// index" exactly.
 #define NN_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ unsigned long long nn_key(float qx, float qy, float qz, const float4 &p)
+{
+  const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+  float d = dx * dx;                                     // cvflann::L2_Simple<float>
+  d += dy * dy;
+  d += dz * dz;
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+}
+#define NN_CONSIDER(P) { const unsigned long long key_ = nn_key(qx, qy, qz, (P)); best = key_ < best ? key_ : best; }
+// a key whose index is NN_IDX_NONE (a dropped pixel: d2 = inf) or NN_KEY_NONE itself means "nothing found"
 #define NN_UNPACK(best, bi, bd)                                            \
   {                                                                        \
-    const bool found_ = (best) != NN_KEY_NONE;                             \
-    *(bi) = found_ ? (int)((best) & 0xFFFFFFFFull) : -1;                   \
+    const unsigned lo_ = (unsigned)((best) & 0xFFFFFFFFull);               \
+    const bool found_ = lo_ < (unsigned)NN_IDX_NONE;                       \
+    *(bi) = found_ ? (int)lo_ : -1;                                        \
     *(bd) = found_ ? __uint_as_float((unsigned)((best) >> 32)) : NAN;      \
   }
 
-// search of the cell rows [cy0, cy1] x [cx0, cx1]; the grid and the sorted cloud are L2-resident
-__device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *__restrict__ sref,
-                                                 const int *__restrict__ cell_start, float qx, float qy, float qz, int cx0,
-                                                 int cx1, int cy0, int cy1, int *bi, float *bd)
+// ---- grid search (fl_icp: caller-supplied clouds) -------------------------------------------------------
+// exact 1-NN among the points of the cell rows [cy0, cy1] x [cx0, cx1]; the grid and the sorted cloud are L2-resident
+__device__ __forceinline__ void nn_search_grid(const NnGrid &S, const float4 *__restrict__ sref,
+                                               const int *__restrict__ cell_start, float qx, float qy, float qz, float r,
+                                               int *bi, float *bd)
 {
   unsigned long long best = NN_KEY_NONE;
   const int last = S.nsorted - 1;
   if (last < 0) { NN_UNPACK(best, bi, bd) return; }
+  int cx0 = 0, cx1 = S.GX - 1, cy0 = 0, cy1 = S.GY - 1;
+  if (isfinite(r)) {
+    cx0 = cell_of(qx - r, S.xmin, S.inv_c, S.GX);
+    cx1 = cell_of(qx + r, S.xmin, S.inv_c, S.GX);
+    cy0 = cell_of(qy - r, S.ymin, S.inv_c, S.GY);
+    cy1 = cell_of(qy + r, S.ymin, S.inv_c, S.GY);
+  }
   // The search is latency-bound and a wave pays for its slowest lane, so round trips are what counts:
   // the headers of 4 grid rows (8 loads) are fetched together, then the candidates of all 4 row segments
   // are enumerated as ONE flat list, FL_ICP_NB per round trip -- a lane needs ceil(total / NB) rounds however the
   // candidates are spread over the rows.  Slots past the end of the list are NOT masked: they read points that
   // follow the last row segment (clamped to the cloud), and looking at extra reference points never changes the
   // answer -- the minimum over a superset that still contains every point within the search radius is the same
-  // nearest neighbour, ties to the lowest index included.  (Chunked per-row reads with no index mapping at all
-  // were measured too: fewer instructions per candidate, but a wave then pays for its longest ROW, not its
-  // longest list: 20.3 ms vs 17.6 ms.)
+  // nearest neighbour, ties to the lowest index included.
   for (int cy = cy0; cy <= cy1; cy += 4) {
     int rb[4], re[4];
 #pragma unroll
@@ -619,17 +643,96 @@ __device__ __forceinline__ void nn_search_global(const NnGrid &S, const float4 *
   NN_UNPACK(best, bi, bd)
 }
 
+// ---- organised search (recognition / detection: the reference cloud is a back-projected crop) ------------
+struct OrgGeom {
+  int cw, ch;            // crop size: refimg[v * cw + u] holds the point of crop pixel (u, v)
+  float offu, offv;      // scene pixel of crop pixel (0, 0) minus the principal point
+  float fx, fy;
+};
+// whole-wave minimum / maximum of an int by DPP (row_shr 1, 2, 4, 8, row_bcast 15 / 31), returned as a wave-uniform value
+#define FL_DPP_RED(OP, IDENT)                                                                                 \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x111, 0xF, 0xF, false));                            \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x112, 0xF, 0xF, false));                            \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x114, 0xF, 0xF, false));                            \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x118, 0xF, 0xF, false));                            \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x142, 0xA, 0xF, false));                            \
+  v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x143, 0xC, 0xF, false));                            \
+  return __builtin_amdgcn_readlane(v, 63);
+__device__ __forceinline__ int wave_min_i(int v) { FL_DPP_RED(min, 0x7fffffff) }
+__device__ __forceinline__ int wave_max_i(int v) { FL_DPP_RED(max, (int)0x80000000) }
+
+// The crop pixels whose points can lie within distance r of q: a point (X, Y, Z) of pixel (su, sv) satisfies
+// su - cx = X fx / Z up to float rounding (it was generated as X = ((su - cx) / fx) Z), and |X - qx|, |Z - qz| <= r.
+// The 0.05-pixel slop is two orders of magnitude above that rounding.  An empty window has u_lo > u_hi.
+__device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy, float qz, float r, int &u_lo, int &u_hi, int &v_lo,
+                                           int &v_hi)
+{
+  u_lo = 0; u_hi = g.cw - 1; v_lo = 0; v_hi = g.ch - 1;
+  const float zlo = qz - r, zhi = qz + r;
+  if (isfinite(r) && zlo > 1.0f) {                       // otherwise the whole crop (valid points have 0 < Z <= 900)
+    const float ilo = __builtin_amdgcn_rcpf(zlo), ihi = __builtin_amdgcn_rcpf(zhi);
+    const float xlo = qx - r, xhi = qx + r, ylo = qy - r, yhi = qy + r;
+    const float ful = floorf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - g.offu - 0.05f);
+    const float fuh = ceilf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.05f);
+    const float fvl = floorf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.05f);
+    const float fvh = ceilf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.05f);
+    const float cwm = (float)(g.cw - 1), chm = (float)(g.ch - 1);
+    if (fuh < 0.f || ful > cwm || fvh < 0.f || fvl > chm) { u_lo = 1; u_hi = 0; return; }
+    u_lo = (int)fmaxf(ful, 0.f);
+    u_hi = (int)fminf(fuh, cwm);
+    v_lo = (int)fmaxf(fvl, 0.f);
+    v_hi = (int)fminf(fvh, chm);
+  }
+}
+
+// every lane's window enumerated in lockstep, maxh rows of maxw positions, 4 positions per batch and the next batch in flight
+// while one is evaluated (lanes with a smaller window re-read their own last column / row: duplicates do not change a
+// minimum); fetch((v - ov) * RS + (u - ou)) returns the point of crop pixel (u, v)
+template <typename F>
+__device__ __forceinline__ unsigned long long org_scan(F fetch, int RS, int ou, int ov, float qx, float qy, float qz, int u_lo, int u_hi,
+                                                       int v_lo, int v_hi, int maxw, int maxh)
+{
+  unsigned long long best = NN_KEY_NONE;
+  const int wl = u_hi - u_lo, hl = v_hi - v_lo;
+  const int b0 = (v_lo - ov) * RS + (u_lo - ou);
+  const int nbw = (maxw + 3) >> 2, nb = nbw * maxh;       // batches per row, batches in all (wave-uniform)
+  float4 cur[4], nxt[4];
+  int du = 0, dv = 0;                                      // of the batch being fetched (wave-uniform)
+  auto fetch_batch = [&](float4 (&p)[4]) {
+    const int rb = b0 + min(dv, hl) * RS;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p[e] = fetch(rb + min(du + e, wl));
+    du += 4;
+    if (du >= maxw) { du = 0; ++dv; }
+  };
+  if (nb > 0) fetch_batch(cur);
+  for (int b = 0; b < nb; b += 2) {                        // ping-pong: no register copies between batches
+    if (b + 1 < nb) fetch_batch(nxt);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+    if (b + 1 < nb) {
+      if (b + 2 < nb) fetch_batch(cur);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) NN_CONSIDER(nxt[e])
+    }
+  }
+  return best;
+}
+
 // ---- getL2distClouds (ICP.cpp:68-111) over the index-paired clouds, optionally fused with the
-// in-place transformPoints that precedes it (ICP.cpp:28-45, 756).  FL_ICP_PARITY: waves 1-3 write
+// in-place transformPoints that precedes it (ICP.cpp:28-45, 756).  FL_ICP_PARITY: the producer waves write
 // the per-point terms into double-buffered LDS tiles while lane 0 of wave 0 adds the previous tile
 // in index order (the reference's `dist_mean += dist` chain); one barrier per tile.
-template <int MODE>
-__device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const float *ref, float *bnd, int n, float thr,
+// Also maintains bnd[i], an upper bound on the distance from model point i to SOME reference point: the index pair
+// before the first iteration (Ropt == nullptr), afterwards the bound grows by how far point i moved (the search
+// replaces it by the distance it found).
+template <int MODE, class SH>
+__device__ __forceinline__ void l2dist_phase(SH &S, float *mod, const float *ref, float *bnd, int n, float thr,
                                              const float *Ropt, const float *Topt)
 {
   constexpr bool parity = MODE == FL_ICP_PARITY;
-  const int TQ = parity ? ICP_BS - 64 : ICP_BS;          // rows per tile: wave 0 only chains in parity mode
-  const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+  constexpr int TQ = parity ? SH::TQ : SH::BS;           // rows per tile: wave 0 only chains in parity mode
+  const int slot = parity ? SH::producer_slot() : (int)threadIdx.x;
   int counter = 0, inl = 0;
   double dsum[1] = {0.0};
   float acc = 0.0f;
@@ -690,13 +793,13 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
       }
       if (parity) S.dtile[t & 1][slot] = term;            // non-inliers add an exact +0.0f
     } else if (t > 0 && threadIdx.x == 0) {
-      acc = chain_tile(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
+      acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
     }
     if (parity) __syncthreads();
 
   }
   if (parity && ntiles > 0 && threadIdx.x == 0)
-    acc = chain_tile(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
+    acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
   counter = block_sum_int(S, counter);
   inl = block_sum_int(S, inl);
   float dm;
@@ -722,14 +825,18 @@ __device__ __forceinline__ void l2dist_phase(IcpShared &S, float *mod, const flo
 }
 
 // ---- icpCloudToCloud_Ex (ICP.cpp:617-809) --------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model,
-                        int it_thr, float dmt, float ddt, fl_icp_result *res)
+// ORG: the reference cloud is also available as the image `og` describes (sref = refimg, perm = tile order), see
+// "Organised search" at the top; otherwise the grid is built here and searched.
+template <int MODE, bool ORG, class SH>
+__device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model,
+                        int it_thr, float dmt, float ddt, fl_icp_result *res, const OrgGeom &og)
 {
+  constexpr int BS = SH::BS, NW = SH::NW;
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
   float4 *sref = (float4 *)(wsb + L.sref);
   int *nn = (int *)(wsb + L.nn);
   float *bnd = (float *)(wsb + L.bnd);
+  const int *perm = (const int *)(wsb + L.perm);
   const float *nrm = (const float *)(wsb + L.nrm);
   int *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
   constexpr bool plane = MODE == FL_ICP_POINT_TO_PLANE;
@@ -760,10 +867,10 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     __syncthreads();
     return;
   }
-  build_grid(S, ref, n_ref, sref, cell_start, cell_cur, L.ncell_max);
+  if (!ORG) build_grid(S, ref, n_ref, sref, cell_start, cell_cur, L.ncell_max);
   TSTAMP(0);
   // copyPoints(pts_model, pts_model_tmp) (:666-667): invalid points become Vec3f() = 0
-  for (int i = threadIdx.x; i < n_model; i += blockDim.x)
+  for (int i = threadIdx.x; i < n_model; i += BS)
     if (!vvalid(mod[3 * i + 2])) { mod[3 * i] = 0.f; mod[3 * i + 1] = 0.f; mod[3 * i + 2] = 0.f; }
   if (threadIdx.x == 0) {
     S.R[0] = S.R[4] = S.R[8] = 1.f;                      // R = eye, T = 0 (:644-645)
@@ -787,68 +894,143 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     constexpr int mode = MODE;
     int kept = 0;
     const bool index_pairs = iter == 1 && !plane;       // :700-704
-    // fast: fp64 per-thread partials.  point-to-plane: the thread's ~60 terms are summed in float32 (27 registers
-    // instead of 54 -- what lets the kernel run 5 workgroups per CU like the parity one) and only the cross-thread tree
-    // runs in fp64; the 6x6 system is re-linearised every iteration, so a 1e-6 relative error in a sum is immaterial.
+    // fast: per-thread partials.  point-to-plane: the thread's ~60 terms are summed in float32 (27 registers
+    // instead of 54) and only the cross-thread tree runs in fp64; the 6x6 system is re-linearised every
+    // iteration, so a 1e-6 relative error in a sum is immaterial.
     typename std::conditional<plane || FL_ICP_FAST_F32 != 0, float, double>::type ds[NSUM];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) ds[k] = 0.0;
+    // a kept pair (model point m, reference point r with index j) enters the sums of the modes that do not chain
+    auto pair_sums = [&](float m0, float m1, float m2, float r0, float r1, float r2, int j) {
+      if (plane) {
+        // linearised point-to-plane: residual e = n.(m - r), Jacobian row J = [m x n, n] wrt (omega, t);
+        // ds = upper triangle of sum J J^T (21) followed by sum J e (6)
+        const F3 nv = ld3_u32(nrm, j);
+        const float n0 = nv.x, n1 = nv.y, n2 = nv.z;
+        const float J[6] = {m1 * n2 - m2 * n1, m2 * n0 - m0 * n2, m0 * n1 - m1 * n0, n0, n1, n2};
+        const float e = n0 * (m0 - r0) + n1 * (m1 - r1) + n2 * (m2 - r2);
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = a; b < 6; ++b) ds[q++] += J[a] * J[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) ds[21 + a] += J[a] * e;
+      } else if (!parity) {
+        const float m[3] = {m0, m1, m2}, r[3] = {r0, r1, r2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) ds[a * 3 + b] += (double)m[a] * (double)r[b];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { ds[9 + q] += (double)m[q]; ds[12 + q] += (double)r[q]; }
+      }
+    };
     if (!index_pairs) {
-      // Phase A1 -- PointsCorresponding (:193-279): all four waves search.  bnd[i] (distance to the partner found
+      // Phase A1 -- PointsCorresponding (:193-279): all waves search.  bnd[i] (distance to the partner found
       // last time plus the motion since; initially the index pair) bounds the search radius, so a converging
-      // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.  Every load
-      // ahead of the search is coalesced and the next query's are issued before this query's search.
+      // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.
       const float r_thr = uniform_f(sqrtf(thr));
-      const NnGrid G = nn_grid(S);
-      int i = threadIdx.x;
-      float qx = 0.f, qy = 0.f, qz = 0.f, qb = 0.f;
-      if (i < n_model) { const F3 q3 = ld3_u32(mod, i); qx = q3.x; qy = q3.y; qz = q3.z; qb = ld_u32(bnd, i); }
-      for (; i < n_model; i += ICP_BS) {
-        const int in = min(i + ICP_BS, n_model - 1);       // clamped: unused past the end
-        const F3 nq3 = ld3_u32(mod, in);
-        const float nqx = nq3.x, nqy = nq3.y, nqz = nq3.z, nqb = ld_u32(bnd, in);
-        int cx0, cx1, cy0, cy1, j = -1;
-        float d = NAN;
-        if (nn_ranges(G, qx, qy, qz, thr, r_thr, qb, &cx0, &cx1, &cy0, &cy1))
-          nn_search_global(G, sref, cell_start, qx, qy, qz, cx0, cx1, cy0, cy1, &j, &d);
-        const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
-        if (keep) ++kept;
-        nn[i] = keep ? j : -1;
-        if (j >= 0) bnd[i] = sqrt_upper(d);               // else: the old partner is still within qb
-        if (plane && keep) {
-          // linearised point-to-plane: residual e = n.(m - r), Jacobian row J = [m x n, n] wrt (omega, t);
-          // ds = upper triangle of sum J J^T (21) followed by sum J e (6)
-          const F3 rv = ld3_u32(ref, j), nv = ld3_u32(nrm, j);
-          const float n0 = nv.x, n1 = nv.y, n2 = nv.z, m0 = qx, m1 = qy, m2 = qz;
-          const float J[6] = {m1 * n2 - m2 * n1, m2 * n0 - m0 * n2, m0 * n1 - m1 * n0, n0, n1, n2};
-          const float e = n0 * (m0 - rv.x) + n1 * (m1 - rv.y) + n2 * (m2 - rv.z);
-          int q = 0;
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) ds[q++] += J[a] * J[b];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) ds[21 + a] += J[a] * e;
+      if (ORG) {
+        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step
+        const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        constexpr int CAPW = (int)(sizeof(S.prod) / 16) / NW;       // points a wave can stage in its share of the chain tiles
+        float4 *stage = (float4 *)&S.prod[0][0][0] + wv * CAPW;
+        const float4 *refimg = sref;
+        const int last_s = n_model - 1;
+        int sb = wv * 64;
+        int i_c = ld_u32(perm, min(sb + lane, last_s));
+        F3 q_c = ld3_u32(mod, i_c);
+        float b_c = ld_u32(bnd, i_c);
+        int i_n = ld_u32(perm, min(sb + NW * 64 + lane, last_s));
+        for (; sb < n_model; sb += NW * 64) {
+          const F3 q_n = ld3_u32(mod, i_n);
+          const float b_n = ld_u32(bnd, i_n);
+          const int i_nn = ld_u32(perm, min(sb + 2 * NW * 64 + lane, last_s));
+          const int i = i_c;
+          const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
+          const bool active = sb + lane < n_model;
+          const bool queryable = active && thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
+          int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
+          if (queryable) org_window(og, qx, qy, qz, nn_radius(qx, qy, qz, fminf(b_c, r_thr)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_thr
+          const bool some = u_lo <= u_hi;
+          const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
+          int j = -1;
+          float d = NAN;
+          if (U1 >= U0) {                                  // wave-uniform: at least one lane has a window
+            const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
+            const int maxw = wave_max_i(u_hi - u_lo + 1), maxh = wave_max_i(v_hi - v_lo + 1);
+            if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }   // lanes without a window look at one staged point: a real
+                                                             // reference point beyond their radius, which the gate drops
+            const int W = U1 - U0 + 1, H = V1 - V0 + 1, area = W * H;
+#ifdef FL_ICP_PHASES
+            if (lane == 0) {
+              atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
+              atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(maxw * maxh));
+              atomicAdd((unsigned long long *)&S.tacc[10], area <= CAPW ? 0ull : 1ull);
+              atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)area);
+              if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(maxw * maxh));
+            }
+#endif
+            unsigned long long best;
+            if (area <= CAPW) {
+              const float invW = 1.0f / (float)W;            // k / W below: exact for k < 2^20 (k + 0.5 keeps clear of the integers)
+              for (int k = lane; k < area; k += 64) {
+                const int row = (int)(((float)k + 0.5f) * invW), col = k - row * W;
+                stage[k] = ld_u32(refimg, (V0 + row) * og.cw + U0 + col);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              best = org_scan([&](int idx) { return stage[idx]; }, W, U0, V0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, maxw, maxh);
+              __builtin_amdgcn_wave_barrier();               // the next step's staging overwrites what this scan read
+            } else {
+              best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, maxw, maxh);
+            }
+            if (queryable) NN_UNPACK(best, &j, &d)
+          }
+          const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
+          if (active) {
+            nn[i] = keep ? j : -1;
+            if (j >= 0) bnd[i] = sqrt_upper(d);               // else: the old partner is still within the old bound
+          }
+          if (keep) {
+            ++kept;
+            if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
+          }
+          i_c = i_n; q_c = q_n; b_c = b_n; i_n = i_nn;
         }
-        if (!parity && !plane && keep) {
-          const float m[3] = {qx, qy, qz}, r[3] = {ref[3 * j], ref[3 * j + 1], ref[3 * j + 2]};
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) ds[a * 3 + b] += (double)m[a] * (double)r[b];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) { ds[9 + q] += (double)m[q]; ds[12 + q] += (double)r[q]; }
+      } else {
+        const NnGrid G = nn_grid(S);
+        int i = threadIdx.x;
+        float qx = 0.f, qy = 0.f, qz = 0.f, qb = 0.f;
+        if (i < n_model) { const F3 q3 = ld3_u32(mod, i); qx = q3.x; qy = q3.y; qz = q3.z; qb = ld_u32(bnd, i); }
+        for (; i < n_model; i += BS) {
+          const int in = min(i + BS, n_model - 1);           // clamped: unused past the end
+          const F3 nq3 = ld3_u32(mod, in);
+          const float nqx = nq3.x, nqy = nq3.y, nqz = nq3.z, nqb = ld_u32(bnd, in);
+          int j = -1;
+          float d = NAN;
+          if (thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz))
+            nn_search_grid(G, sref, cell_start, qx, qy, qz, nn_radius(qx, qy, qz, fminf(qb, r_thr)), &j, &d);
+          const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
+          nn[i] = keep ? j : -1;
+          if (j >= 0) bnd[i] = sqrt_upper(d);               // else: the old partner is still within qb
+          if (keep) {
+            ++kept;
+            if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
+          }
+          qx = nqx; qy = nqy; qz = nqz; qb = nqb;
         }
-        qx = nqx; qy = nqy; qz = nqz; qb = nqb;
       }
       __syncthreads();                                   // nn[] complete
       TSTAMP(2);
     }
-    // Phase A2 (iteration 1: the only phase): rows in index order.  Parity mode: waves 1-3 write
+    // Phase A2 (iteration 1: the only phase): rows in index order.  Parity mode: the producer waves write
     // the 15 scalars of each row into double-buffered LDS tiles, wave 0 adds the previous tile
     // in row order -- getMean (:8-25) and the covariance loop (:731-735) as 15 float32 chains.
-    const int TQ = parity ? ICP_BS - 64 : ICP_BS;
-    const int slot = parity ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+    constexpr int TQ = parity ? SH::TQ : BS;
+    const int slot = parity ? SH::producer_slot() : (int)threadIdx.x;
     const int ntiles = (parity || index_pairs) ? (rows + TQ - 1) / TQ : 0;
     float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
     if (parity && iter > 1) {
@@ -876,7 +1058,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           const F3 r2v = ld3_u32(ref, g);
           const float r2[3] = {r2v.x, r2v.y, r2v.z};
           const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f: (+0) * (+0)
-          float (*tile)[ICP_TS] = S.prod[t & 1];
+          float (*tile)[SH::TS] = S.prod[t & 1];
           float mm[3], rr[3];
 #pragma unroll
           for (int q = 0; q < 3; ++q) { mm[q] = have ? m1[q] : 0.0f; rr[q] = have ? r1[q] : 0.0f; }
@@ -891,7 +1073,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           for (int q = 0; q < 3; ++q) { m1[q] = m2[q]; r1[q] = r2[q]; m2[q] = m3[q]; }
           j2 = j3;
         } else if (t > 0 && threadIdx.x < 15) {
-          acc = chain_tile(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+          acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
         }
         __syncthreads();
       }
@@ -920,7 +1102,7 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
         }
         if (parity) {
           // dropped pairs contribute an exact +0.0f, so the chains are branch-free
-          float (*tile)[ICP_TS] = S.prod[t & 1];
+          float (*tile)[SH::TS] = S.prod[t & 1];
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -936,12 +1118,12 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           for (int q = 0; q < 3; ++q) { ds[9 + q] += have_m ? (double)m[q] : 0.0; ds[12 + q] += (double)r[q]; }
         }
       } else if (t > 0 && threadIdx.x < 15) {
-        acc = chain_tile(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+        acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
       }
       if (parity) __syncthreads();
     }
     if (parity && ntiles > 0 && threadIdx.x < 15)
-      acc = chain_tile(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, rows - (ntiles - 1) * TQ), acc);
+      acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, rows - (ntiles - 1) * TQ), acc);
     kept = block_sum_int(S, kept);
     TSTAMP(3);
     const int ncm = index_pairs ? n_model : kept, ncr = index_pairs ? n_ref : kept;
@@ -996,12 +1178,12 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
           // Rodrigues: R = I + (sin t / t) K + ((1 - cos t) / t^2) K^2, K = [omega]x
           const double wx = x[0], wy = x[1], wz = x[2], t2 = wx * wx + wy * wy + wz * wz, t = sqrt(t2);
           const double sa = t > 1.0e-9 ? sin(t) / t : 1.0 - t2 / 6.0, sb = t > 1.0e-9 ? (1.0 - cos(t)) / t2 : 0.5 - t2 / 24.0;
-          const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+          const double Kx[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
           for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
               double k2 = 0;
-              for (int k = 0; k < 3; ++k) k2 += K[i * 3 + k] * K[k * 3 + j];
-              S.Ropt[i * 3 + j] = (float)((i == j ? 1.0 : 0.0) + sa * K[i * 3 + j] + sb * k2);
+              for (int k = 0; k < 3; ++k) k2 += Kx[i * 3 + k] * Kx[k * 3 + j];
+              S.Ropt[i * 3 + j] = (float)((i == j ? 1.0 : 0.0) + sa * Kx[i * 3 + j] + sb * k2);
             }
           for (int k = 0; k < 3; ++k) S.Topt[k] = (float)x[3 + k];
         }
@@ -1061,6 +1243,11 @@ __device__ __forceinline__ void icp_run(IcpShared &S, uint8_t *wsb, const IcpWsL
     for (int i = 0; i < 6; ++i) res->R[i] = (float)S.tacc[i];
     res->R[6] = (float)S.tacc[6];
     res->R[7] = (float)(clock64() - S.tkernel);
+    res->R[8] = (float)S.tacc[8];                       // organised search: steps, candidates, fallbacks
+    res->T[0] = (float)S.tacc[9];
+    res->T[1] = (float)S.tacc[10];
+    res->T[2] = (float)S.tacc[11];
+    res->dist_mean = (float)S.tacc[12];
 #endif
   }
   __syncthreads();
@@ -1098,21 +1285,22 @@ __device__ __forceinline__ void scene_normal(const uint16_t *__restrict__ scene,
   n[0] = c[0] / len; n[1] = c[1] / len; n[2] = c[2] / len;
 }
 
-__device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
-                           const int *rm, const int *rr, float *ref, float *mod, float *nrm)
+template <class SH>
+__device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
+                           const int *rm, const int *rr, float *ref, float *mod, float *nrm, float4 *refimg)
 {
+  constexpr int BS = SH::BS, NW = SH::NW;
   const int cw = rm[2], ch = rm[3], np = cw * ch;
   const float inv_fx = 1.0f / a.fx, inv_fy = 1.0f / a.fy;                        // depth_to_3d.cpp:103-104
   const float minv_fx = 1.0f / 608.f, minv_fy = 1.0f / 608.f;                   // initInternalMat common.cpp:358
   const float zs = (float)(1 / 1000.0);
-  // Row-major compaction of the paired-valid pixels.  Per 256 pixels: rank inside the wave by ballot + mbcnt, the four
-  // wave counts through a double-buffered LDS slot -- ONE barrier per step (the block-wide scan it replaces took
-  // five, and with 5 workgroups per CU the barriers were the cost); every thread keeps the running total itself.
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  // Row-major compaction of the paired-valid pixels.  Per BS pixels: rank inside the wave by ballot + mbcnt, the
+  // wave counts through a double-buffered LDS slot -- ONE barrier per step; every thread keeps the running total itself.
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float inv_cw = 1.0f / (float)cw;                   // p / cw below: exact for p < 2^20, cw <= 2^10 (see div_small)
   int kept_before = 0, step = 0;
   __syncthreads();
-  for (int base = 0; base < np; base += blockDim.x, ++step) {
+  for (int base = 0; base < np; base += BS, ++step) {
     const int p = base + threadIdx.x;
     float A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
     int keep = 0;
@@ -1141,7 +1329,12 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
     if (lane == 0) slot[wv] = __popcll(bal);
     __syncthreads();
     int before = 0, total = 0;
-    for (int i = 0; i < nwv; ++i) { const int c = slot[i]; before += i < wv ? c : 0; total += c; }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { const int c = slot[i]; before += i < wv ? c : 0; total += c; }
+    // the reference cloud as an image (organised search): the point and its index, or a point at infinity
+    if (p < np)
+      refimg[p] = keep ? make_float4(A[0], A[1], A[2], __int_as_float(kept_before + before + in_wave))
+                       : make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(NN_IDX_NONE));
     if (keep) {
       const int k = kept_before + before + in_wave;
       ref[3 * k] = A[0]; ref[3 * k + 1] = A[1]; ref[3 * k + 2] = A[2];
@@ -1158,22 +1351,94 @@ __device__ __forceinline__ int crop_clouds(IcpShared &S, const IcpArgs &a, const
   return kept_before;
 }
 
-// icpCloudToCloud_Ex on clouds the host staged in the workspace (fl_icp)
-template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) void k_icp_clouds(IcpArgs a)
+// The model indices in 8x8-pixel tile order (tile rows alternately left-to-right and right-to-left, so consecutive tiles
+// are neighbours): the 64 queries a wave takes per step then project into a compact window of the reference image.
+// Index k of crop pixel p is refimg[p].w (the paired compaction keeps the same pixels of both clouds).
+template <class SH>
+__device__ __forceinline__ void build_tile_order(SH &S, const float4 *refimg, int cw, int ch, int n, int *perm)
 {
-  extern __shared__ __align__(16) uint8_t icp_smem[];
-  IcpShared &S = *(IcpShared *)icp_smem;
-  const IcpWsLayout L = icp_layout(a.n_max);
-  uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
-  icp_run<MODE>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp);
+  constexpr int BS = SH::BS, NW = SH::NW;
+  int *cnt = (int *)&S.prod[0][0][0];
+  constexpr int CAP = (int)(sizeof(S.prod) / 4);
+  const int ntx = (cw + 7) >> 3, nty = (ch + 7) >> 3, ntile = ntx * nty;
+  if (ntile > CAP) {                                       // more tiles than the scratch holds (crops beyond 1.5 Mpixel): index order
+    for (int i = threadIdx.x; i < n; i += BS) perm[i] = i;
+    __syncthreads();
+    return;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float inv_ntx = 1.0f / (float)ntx;
+  auto tile_index = [&](int t, bool &has) {
+    const int ty = (int)(((float)t + 0.5f) * inv_ntx);
+    int tx = t - ty * ntx;
+    if (ty & 1) tx = ntx - 1 - tx;
+    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    int k = NN_IDX_NONE;
+    if (x < cw && y < ch) k = __float_as_int(refimg[y * cw + x].w);
+    has = (unsigned)k < (unsigned)NN_IDX_NONE;
+    return k;
+  };
+  for (int t = wv; t < ntile; t += NW) {
+    bool has;
+    tile_index(t, has);
+    const unsigned long long bal = __ballot(has);
+    if (lane == 0) cnt[t] = __popcll(bal);
+  }
+  __syncthreads();
+  // exclusive scan of cnt[0 .. ntile) in place: a contiguous chunk per thread, the thread totals scanned by shuffles and
+  // one LDS round
+  {
+    const int per = (ntile + BS - 1) / BS, lo = min((int)threadIdx.x * per, ntile), hi = min(lo + per, ntile);
+    int mine = 0;
+    for (int t = lo; t < hi; ++t) mine += cnt[t];
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) S.iscan[wv] = inc;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) before += w < wv ? S.iscan[w] : 0;
+    int ex = before + inc - mine;
+    for (int t = lo; t < hi; ++t) { const int c = cnt[t]; cnt[t] = ex; ex += c; }
+  }
+  __syncthreads();
+  for (int t = wv; t < ntile; t += NW) {
+    bool has;
+    const int k = tile_index(t, has);
+    const unsigned long long bal = __ballot(has);
+    if (has) perm[cnt[t] + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = k;
+  }
+  __syncthreads();
 }
 
-template <int MODE>
-__global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(ICP_MODE_WPE(MODE), ICP_MODE_WPE(MODE) > 4 ? ICP_MODE_WPE(MODE) : (MODE == FL_ICP_PARITY ? FL_ICP_WPE : 4)))) void k_icp_pipeline(IcpArgs a)
+// waves per SIMD a kernel instance is compiled for: the 256-thread one shares a CU with up to ICP_MODE_WPE - 1 others,
+// a 1024-thread workgroup is 4 waves per SIMD by itself
+#define ICP_WPE(MODE, BS) ((BS) == ICP_BS_SMALL ? ICP_MODE_WPE(MODE) : (BS) / 256)
+
+// icpCloudToCloud_Ex on clouds the host staged in the workspace (fl_icp)
+template <int MODE, int BS>
+__global__ __launch_bounds__(BS) void k_icp_clouds(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
-  IcpShared &S = *(IcpShared *)icp_smem;
+  using SH = IcpSharedT<BS>;
+  SH &S = *(SH *)icp_smem;
+  const IcpWsLayout L = icp_layout(a.n_max);
+  uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
+  const OrgGeom none = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  icp_run<MODE, false>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp, none);
+}
+
+template <int MODE, int BS>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(ICP_WPE(MODE, BS), ICP_WPE(MODE, BS) > 4 ? ICP_WPE(MODE, BS) : 4)))
+void k_icp_pipeline(IcpArgs a)
+{
+  extern __shared__ __align__(16) uint8_t icp_smem[];
+  using SH = IcpSharedT<BS>;
+  SH &S = *(SH *)icp_smem;
 #ifdef FL_ICP_PHASES
   if (threadIdx.x == 0) S.tkernel = clock64();
 #endif
@@ -1181,7 +1446,6 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)job * a.ws_stride;
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
-
 
   fl_recognition_result *res = &a.results[job];
   const uint16_t *scene, *model;
@@ -1246,31 +1510,35 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       return;
     }
   }
+  float4 *refimg = (float4 *)(wsb + L.sref);
   const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod,
-                             MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr);
+                             MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr, refimg);
+  const OrgGeom og = {S.rect_r[2], S.rect_r[3], (float)S.rect_r[0] - a.cx, (float)S.rect_r[1] - a.cy, a.fx, a.fy};
+  build_tile_order(S, refimg, og.cw, og.ch, np, (int *)(wsb + L.perm));
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
   if (MODE == FL_ICP_PARITY) {
-    // getMean x2 as six float32 chains in index order, fed like phase A2: waves 1..3 load 192 rows per tile
+    // getMean x2 as six float32 chains in index order, fed like phase A2: the producer waves load TQ rows per tile
     // (coalesced 12-byte loads) into the LDS tiles, lanes 0..5 of wave 0 add the previous tile
     {
-      const int slot = (int)threadIdx.x - 64, ntiles = (np + ICP_TQ - 1) / ICP_TQ;
+      constexpr int TQ = SH::TQ;
+      const int slot = SH::producer_slot(), ntiles = (np + TQ - 1) / TQ;
       float acc = 0.0f;
       for (int t = 0; t < ntiles; ++t) {
         if (slot >= 0) {
-          const int i = t * ICP_TQ + slot;
+          const int i = t * TQ + slot;
           F3 m3 = {0.f, 0.f, 0.f}, r3 = {0.f, 0.f, 0.f};
           if (i < np) { m3 = ld3_u32(mod, i); r3 = ld3_u32(ref, i); }
-          float (*tile)[ICP_TS] = S.prod[t & 1];
+          float (*tile)[SH::TS] = S.prod[t & 1];
           tile[0][slot] = m3.x; tile[1][slot] = m3.y; tile[2][slot] = m3.z;
           tile[3][slot] = r3.x; tile[4][slot] = r3.y; tile[5][slot] = r3.z;
         } else if (t > 0 && threadIdx.x < 6) {
-          acc = chain_tile(S.prod[(t - 1) & 1][threadIdx.x], min(ICP_TQ, np - (t - 1) * ICP_TQ), acc);
+          acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, np - (t - 1) * TQ), acc);
         }
         __syncthreads();
       }
       if (ntiles > 0 && threadIdx.x < 6)
-        acc = chain_tile(S.prod[(ntiles - 1) & 1][threadIdx.x], min(ICP_TQ, np - (ntiles - 1) * ICP_TQ), acc);
+        acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, np - (ntiles - 1) * TQ), acc);
       if (threadIdx.x < 6) S.sums[threadIdx.x] = acc;
     }
     __syncthreads();
@@ -1279,7 +1547,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
       for (int k = 0; k < 3; ++k) { mc[k] /= (float)np; rc[k] /= (float)np; }
   } else {
     double ds[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < np; i += blockDim.x)
+    for (int i = threadIdx.x; i < np; i += BS)
       for (int k = 0; k < 3; ++k) { ds[k] += mod[3 * i + k]; ds[3 + k] += ref[3 * i + k]; }
     block_sum_double<6>(S, ds);
     if (np > 0)
@@ -1288,7 +1556,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
   float t_tmp[3], t_init[3];
   for (int k = 0; k < 3; ++k) { t_tmp[k] = rc[k] - mc[k]; t_init[k] = t_tmp[k] + t_match[k]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < np; i += blockDim.x) {   // transformPoints(pts_mod, I, t_match_tmp) :206
+  for (int i = threadIdx.x; i < np; i += BS) {           // transformPoints(pts_mod, I, t_match_tmp) :206
     if (!vvalid(mod[3 * i + 2])) continue;
     const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     float v[3] = {mod[3 * i], mod[3 * i + 1], mod[3 * i + 2]}, o[3];
@@ -1298,7 +1566,7 @@ __global__ __launch_bounds__(ICP_MAX_THREADS) __attribute__((amdgpu_waves_per_eu
     mod[3 * i + 2] = o[2] + t_tmp[2];
   }
   __syncthreads();
-  icp_run<MODE>(S, wsb, L, np, np, a.it_thr, a.dmt, a.ddt, &res->det.icp);      // :228
+  icp_run<MODE, true>(S, wsb, L, np, np, a.it_thr, a.dmt, a.ddt, &res->det.icp, og);      // :228
   if (threadIdx.x == 0) {
     const fl_icp_result &ic = res->det.icp;
     float Rt[3];
@@ -1360,30 +1628,47 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
   return FL_OK;
 }
 
-static int icp_threads(int) { return ICP_BS; }
-static size_t icp_lds_bytes() { return (sizeof(IcpShared) + 15) & ~(size_t)15; }
-static_assert(sizeof(IcpShared) + 16 <= 160 * 1024 / FL_ICP_WPE, "IcpShared must leave room for FL_ICP_WPE workgroups per CU");
-template <typename K>
-static int icp_launch_one(fl_context *ctx, K kern, int n_frames, const IcpArgs &a)
+static_assert(sizeof(IcpSharedT<ICP_BS_SMALL>) + 16 <= 160 * 1024 / FL_ICP_WPE, "IcpSharedT<256> must leave room for FL_ICP_WPE workgroups per CU");
+static_assert(sizeof(IcpSharedT<ICP_BS_WIDE>) + 16 <= 160 * 1024, "IcpSharedT<1024> must fit the CU's LDS");
+template <int BS, typename K>
+static int icp_launch_one(fl_context *ctx, K kern, int n_jobs, const IcpArgs &a)
 {
-  const size_t lds = icp_lds_bytes();
+  const size_t lds = (sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15;
   FL_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(n_frames), dim3(icp_threads(n_frames)), lds, ctx->stream, a);
+  hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(BS), lds, ctx->stream, a);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
 }
-static int icp_launch(fl_context *ctx, int n_frames, const IcpArgs &a)
+// Workgroup width by batch size: with no more jobs than CUs every job runs alone on its CU whatever its width, so it
+// gets the 1024-thread kernel (FL_ICP_WIDE=0/1 forces one or the other: dev knob)
+static bool icp_wide(fl_context *ctx, int n_jobs)
 {
-  if (a.mode != FL_ICP_PARITY && a.mode != FL_ICP_FAST && a.mode != FL_ICP_POINT_TO_PLANE)
-    return fl_set_error(ctx, FL_ERR_INVALID, "unknown fl_icp_mode");
-  if (a.job.kind == 2) {
-    if (a.mode == FL_ICP_POINT_TO_PLANE) return icp_launch_one(ctx, k_icp_clouds<FL_ICP_POINT_TO_PLANE>, n_frames, a);
-    return a.mode == FL_ICP_FAST ? icp_launch_one(ctx, k_icp_clouds<FL_ICP_FAST>, n_frames, a)
-                                 : icp_launch_one(ctx, k_icp_clouds<FL_ICP_PARITY>, n_frames, a);
+  static const char *env = getenv("FL_ICP_WIDE");
+  if (env && env[0] == '0') return false;
+  if (env && env[0] == '1') return true;
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  return n_jobs <= cus;
+}
+template <int MODE>
+static int icp_launch_mode(fl_context *ctx, int n_jobs, const IcpArgs &a)
+{
+  const bool wide = icp_wide(ctx, n_jobs);
+  if (a.job.kind == 2)
+    return wide ? icp_launch_one<ICP_BS_WIDE>(ctx, k_icp_clouds<MODE, ICP_BS_WIDE>, n_jobs, a)
+                : icp_launch_one<ICP_BS_SMALL>(ctx, k_icp_clouds<MODE, ICP_BS_SMALL>, n_jobs, a);
+  return wide ? icp_launch_one<ICP_BS_WIDE>(ctx, k_icp_pipeline<MODE, ICP_BS_WIDE>, n_jobs, a)
+              : icp_launch_one<ICP_BS_SMALL>(ctx, k_icp_pipeline<MODE, ICP_BS_SMALL>, n_jobs, a);
+}
+static int icp_launch(fl_context *ctx, int n_jobs, const IcpArgs &a)
+{
+  switch (a.mode) {
+    case FL_ICP_PARITY: return icp_launch_mode<FL_ICP_PARITY>(ctx, n_jobs, a);
+    case FL_ICP_FAST: return icp_launch_mode<FL_ICP_FAST>(ctx, n_jobs, a);
+    case FL_ICP_POINT_TO_PLANE: return icp_launch_mode<FL_ICP_POINT_TO_PLANE>(ctx, n_jobs, a);
+    default: return fl_set_error(ctx, FL_ERR_INVALID, "unknown fl_icp_mode");
   }
-  if (a.mode == FL_ICP_POINT_TO_PLANE) return icp_launch_one(ctx, k_icp_pipeline<FL_ICP_POINT_TO_PLANE>, n_frames, a);
-  return a.mode == FL_ICP_FAST ? icp_launch_one(ctx, k_icp_pipeline<FL_ICP_FAST>, n_frames, a)
-                               : icp_launch_one(ctx, k_icp_pipeline<FL_ICP_PARITY>, n_frames, a);
 }
 
 static int icp_clouds(fl_context *ctx, const float *ref, const float *ref_normals, int n_ref, const float *model, int n_model,
@@ -1578,3 +1863,4 @@ int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsic
   a.results = det->d_results;
   return icp_launch(ctx, n_frames, a);
 }
+

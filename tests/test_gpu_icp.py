@@ -227,8 +227,11 @@ def test_multi_hypothesis_topk_and_nms(ctx, oracle):
 # Yardsticks: tests/p2plane_model.py (an independent numpy/scipy statement of the same algorithm) and the
 # ground-truth pose of the synthetic scene.
 def _angle_deg(Ra, Rb):
-    c = (np.trace(np.asarray(Ra, np.float64) @ np.asarray(Rb, np.float64).T) - 1) / 2
-    return float(np.degrees(np.arccos(np.clip(c, -1, 1))))
+    """Rotation angle of Ra Rb^T from its skew part and its trace (atan2): accurate for small angles, where the
+    arccos of a trace made of float32-rounded entries resolves nothing below 0.03 degrees."""
+    M = np.asarray(Ra, np.float64) @ np.asarray(Rb, np.float64).T
+    s = 0.5 * np.linalg.norm([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
+    return float(np.degrees(np.arctan2(s, (np.trace(M) - 1) / 2)))
 
 
 def _bbox(m):

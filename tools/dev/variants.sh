@@ -5,5 +5,5 @@ BASE="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-mat
 for v in "$@"; do
   rm -f *.o
   make -s CXXFLAGS="$BASE $v" 2>&1 | grep error
-  (cd ../.. && timeout -k 10 200 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --batch ${B:-1280} ${ARGS:-} 2>&1 | grep -o "icp phase.*\|\"value[^,]*\|stage_ms_last_step[^}]*" | sed "s/^/[$v] /" | cut -c1-400; echo)
+  (cd ../.. && timeout -k 10 200 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --batch ${B:-1280} ${ARGS:-} 2>&1 | grep -o "icp phase.*\|icp organised.*\|\"value[^,]*\|stage_ms_last_step[^}]*" | sed "s/^/[$v] /" | cut -c1-400; echo)
 done
