@@ -99,6 +99,8 @@ SIGNATURES = {
     "fl_match_quantized": (_I, [_P, C.POINTER(_P), _I, _F, _P, _I, C.POINTER(_I)]),
     "fl_match_frame": (_I, [_P, _P, _P, _I, _F, _P, _I, C.POINTER(_I)]),
     "fl_match_frame_masked": (_I, [_P, _P, _P, C.POINTER(_P), _I, _F, _P, _I, C.POINTER(_I)]),
+    "fl_match_batch_submit": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, _F]),
+    "fl_match_batch_collect": (_I, [_P, _I, _P, _I, C.POINTER(_I)]),
     "fl_similarity_maps": (_I, [_P, _I, _I, _P]),
     "fl_last_quantized": (_I, [_P, _P]),
     "fl_recognize_batch": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, C.POINTER(Intrinsics),

@@ -210,9 +210,9 @@ class Detector:
     def finalize(self, w0, h0, max_batch=1, max_candidates=0):
         # model depth renders first (class order = sorted class ids)
         for ci, b in enumerate(self.banks):
-            if b.model_depths and len(b.model_depths) == b.n_pyramids:
+            if b.model_depths:             # the leading pyramids' renders (bank.py); the rest have none and cannot be refined
                 d = np.ascontiguousarray(np.stack(b.model_depths), np.uint16)
-                self.ctx.check(self.lib.fl_detector_set_model_depths(self.h, ci, 0, b.n_pyramids, _ptr(d), d.shape[2],
+                self.ctx.check(self.lib.fl_detector_set_model_depths(self.h, ci, 0, len(b.model_depths), _ptr(d), d.shape[2],
                                                                      d.shape[1], L.FL_MEM_HOST))
         self.ctx.check(self.lib.fl_detector_finalize(self.h, w0, h0, max_batch, max_candidates))
         self.w0, self.h0, self.max_batch = w0, h0, max_batch
@@ -244,6 +244,26 @@ class Detector:
         self.ctx.check(self.lib.fl_match_frame_masked(self.h, _ptr(bgr), _ptr(depth) if depth is not None else None, mp,
                                                       L.FL_MEM_HOST, threshold, _ptr(out), cap, C.byref(n)))
         return out[:min(n.value, cap)], n.value
+
+    def match_batch_submit(self, bgr_ptrs, depth_ptrs, threshold, mem=L.FL_MEM_DEVICE):
+        """Detector::match of a batch of frames (raw pointers, device memory by default); queued, not waited for."""
+        n = len(bgr_ptrs)
+        bp = (C.c_void_p * n)(*bgr_ptrs)
+        dp = (C.c_void_p * n)(*depth_ptrs) if depth_ptrs is not None else None
+        self.ctx.check(self.lib.fl_match_batch_submit(self.h, n, bp, dp, mem, threshold))
+
+    def match_batch_collect(self, frame, cap=65536):
+        out = np.zeros(cap, MATCH_DTYPE)
+        n = C.c_int(0)
+        self.ctx.check(self.lib.fl_match_batch_collect(self.h, frame, _ptr(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)], n.value
+
+    def match_batch(self, bgrs, depths, threshold, cap=65536):
+        """Host arrays in: list of (matches, n_total) per frame."""
+        bs = [np.ascontiguousarray(b, np.uint8) for b in bgrs]
+        ds = [np.ascontiguousarray(d, np.uint16) for d in depths]
+        self.match_batch_submit([b.ctypes.data for b in bs], [d.ctypes.data for d in ds], threshold, L.FL_MEM_HOST)
+        return [self.match_batch_collect(i, cap) for i in range(len(bs))]
 
     def similarity_maps(self, first, count):
         g = self.T[-1]

@@ -24,7 +24,8 @@ class TemplateBank:
         self._features = []       # list of (n,3) int arrays
         self._nfeat = 0
         self.poses = []           # list of 13 floats
-        self.model_depths = []    # list of (h,w) uint16 arrays in 0.1 mm, or empty
+        self.model_depths = []    # list of (h,w) uint16 arrays in 0.1 mm: the depth renders of the FIRST len(model_depths)
+                                  # pyramids (pyramids without one -- random throughput templates -- must come last)
         self._frozen = None
 
     @property
@@ -74,7 +75,7 @@ class TemplateBank:
                 tl.append(dict(width=int(h["width"]), height=int(h["height"]), offset_x=int(h["offset_x"]),
                                offset_y=int(h["offset_y"]), pyramid_level=int(h["pyramid_level"]),
                                features=np.stack([fr["x"], fr["y"], fr["label"]], axis=1)))
-            md = self.model_depths[i] if len(self.model_depths) == self.n_pyramids else None
+            md = self.model_depths[i] if i < len(self.model_depths) else None
             out.add_pyramid(tl, p[i], md)
         return out
 

@@ -148,6 +148,7 @@ struct fl_detector {
   int n_pts_max = 0;
   int last_batch = 0;
   bool last_from_images = false;
+  bool last_match_only = false;          // the last batch was fl_match_batch_submit (no ICP stage to time)
 
   // results
   fl_recognition_result *d_results = nullptr;   // max_batch
@@ -160,6 +161,7 @@ struct fl_detector {
 };
 
 int fl_apply_class_filter(fl_detector *det);
+void fl_update_stage_times(fl_detector *det, int n_frames, const fl_recognition_result *results);
 
 // ---- stage launchers (defined in the per-domain .hip files) ---------------------------------
 // linemod

@@ -1022,6 +1022,19 @@ extern "C" int fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16
   return fl_match_frame_masked(det, bgr, depth, nullptr, mem, threshold, out, cap, n_total);
 }
 
+// the sorted, de-duplicated matches of frame `frame` of the batch last queued with fl_match_batch_submit (or any other
+// fl_match_* / fl_recognize_* call: the lists stay in HBM until the next batch)
+extern "C" int fl_match_batch_collect(fl_detector *det, int frame, fl_match *out, int cap, int *n_total)
+{
+  if (!det || cap < 0 || (cap > 0 && !out)) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || frame < 0 || frame >= det->last_batch) return fl_set_error(ctx, FL_ERR_STATE, "no such frame in the last batch");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  fl_update_stage_times(det, det->last_batch, nullptr);
+  return read_matches(det, frame, out, cap, n_total);
+}
+
 extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16_t *out)
 {
   if (!det || !out || first < 0 || count <= 0) return FL_ERR_INVALID;

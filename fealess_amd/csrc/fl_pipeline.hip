@@ -22,18 +22,19 @@ static bool uniform_stride(const void *const *ptrs, int n, size_t min_bytes, siz
 }
 
 // argument checks, frame staging, front-end and Detector::match of a batch; the depth frames' device location comes back
+// (K == nullptr: Detector::match only, no intrinsics to check)
 static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth, int mem,
-                           const fl_intrinsics *K, const fl_recognition_params *params, const uint16_t **depth_base_out,
+                           const fl_intrinsics *K, float threshold, const uint16_t **depth_base_out,
                            size_t *depth_stride_out, int *host_buf_out)
 {
   int host_buf = -1;     // the input buffer the batch was uploaded to (host frames), released by input_done()
-  if (!det || !bgr || !K || !params || n_frames <= 0) return FL_ERR_INVALID;
+  if (!det || !bgr || n_frames <= 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
   if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
   if (n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames %d > max_batch %d", n_frames, det->max_batch);
   if (det->M == 2 && !depth) return fl_set_error(ctx, FL_ERR_INVALID, "depth frames required (2 modalities)");
   // PrepareInputData (obj_reco_lmicp.cpp:216-259): image size must equal the intrinsics' size
-  if (K->width != det->w0 || K->height != det->h0)
+  if (K && (K->width != det->w0 || K->height != det->h0))
     return fl_set_error(ctx, FL_ERR_INVALID, "intrinsics are %dx%d, detector finalized for %dx%d", K->width, K->height,
                         det->w0, det->h0);
   for (int i = 0; i < n_frames; ++i)
@@ -96,12 +97,39 @@ static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const 
   FL_HIP(ctx, hipEventRecord(det->ev[0], ctx->stream));
   int rc = fl_launch_frontend(det, n_frames, bgr_base, bgr_stride, depth_base, depth_stride, true);
   if (rc) return rc;
-  rc = fl_launch_match_core(det, n_frames, params->matching_threshold);
+  rc = fl_launch_match_core(det, n_frames, threshold);
   if (rc) return rc;
   *depth_base_out = depth_base;
   *depth_stride_out = depth_stride;
   *host_buf_out = host_buf;
   return FL_OK;
+}
+
+// per-stage device times of the batch that was just synchronised (HIP events recorded on the launch stream)
+void fl_update_stage_times(fl_detector *det, int n_frames, const fl_recognition_result *results)
+{
+  if (!det->have_times) return;
+  fl_stage_times &t = det->times;
+  memset(&t, 0, sizeof(t));
+  float ms = 0;
+  auto el = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, det->ev[a], det->ev[b]); return ms; };
+  t.frontend_ms = el(0, 1);
+  t.linmem_ms = el(1, 2);
+  t.scan_ms = el(2, 3);
+  t.refine_ms = el(3, 4);
+  if (det->lazy) {
+    for (int l = 0; l + 1 < det->L; ++l) t.lazy_frontend_ms += el(8 + 2 * l, 9 + 2 * l);
+    t.refine_ms -= t.lazy_frontend_ms;
+  }
+  t.sort_ms = el(4, 5);
+  t.icp_ms = det->last_match_only ? 0.f : el(5, 6);
+  t.total_ms = el(0, 6);
+  t.backproject_ms = 0;                 // fused into the per-frame ICP workgroup
+  t.icp_launches = det->last_match_only ? 0 : 1;
+  if (results)
+    for (int i = 0; i < n_frames; ++i) t.icp_iters_total += results[i].found ? results[i].det.icp.iters : 0;
+  t.scan_algorithmic_bytes = det->scan_bytes_per_frame * n_frames;
+  det->have_times = false;
 }
 
 // after the last kernel that reads the batch's frames has been queued: the copy stream may reuse the buffer after it
@@ -121,7 +149,8 @@ extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t
   const uint16_t *depth_base = nullptr;
   size_t depth_stride = 0;
   int host_buf = -1;
-  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride, &host_buf);
+  if (!K || !params) return FL_ERR_INVALID;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params->matching_threshold, &depth_base, &depth_stride, &host_buf);
   if (rc) return rc;
   fl_context *ctx = det->ctx;
   FL_HIP(ctx, hipMemsetAsync(det->d_results, 0, sizeof(fl_recognition_result) * (size_t)n_frames, ctx->stream));
@@ -133,6 +162,27 @@ extern "C" int fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t
                              hipMemcpyDeviceToHost, ctx->stream));
   det->last_batch = n_frames;
   det->last_from_images = true;
+  det->last_match_only = false;
+  return FL_OK;
+}
+
+// Detector::match (linemod.cpp:1356-1441) for a batch of frames: the reference is called once per camera frame; here
+// front-end and match of n_frames frames are queued together and the sorted match lists stay in HBM until
+// fl_match_batch_collect / fl_export_topk reads them.
+extern "C" int fl_match_batch_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                                     int mem, float threshold)
+{
+  const uint16_t *depth_base = nullptr;
+  size_t depth_stride = 0;
+  int host_buf = -1;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, nullptr, threshold, &depth_base, &depth_stride, &host_buf);
+  if (rc) return rc;
+  fl_context *ctx = det->ctx;
+  if ((rc = input_done(det, host_buf))) return rc;
+  FL_HIP(ctx, hipEventRecord(det->ev[6], ctx->stream));
+  det->last_batch = n_frames;
+  det->last_from_images = true;
+  det->last_match_only = true;
   return FL_OK;
 }
 
@@ -144,28 +194,7 @@ extern "C" int fl_recognize_collect(fl_detector *det, int n_frames, fl_recogniti
   FL_HIP(ctx, hipSetDevice(ctx->device));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(results, det->h_results, sizeof(fl_recognition_result) * (size_t)n_frames);
-  if (det->have_times) {
-    fl_stage_times &t = det->times;
-    memset(&t, 0, sizeof(t));
-    float ms = 0;
-    auto el = [&](int a, int b) { ms = 0; (void)hipEventElapsedTime(&ms, det->ev[a], det->ev[b]); return ms; };
-    t.frontend_ms = el(0, 1);
-    t.linmem_ms = el(1, 2);
-    t.scan_ms = el(2, 3);
-    t.refine_ms = el(3, 4);
-    if (det->lazy) {
-      for (int l = 0; l + 1 < det->L; ++l) t.lazy_frontend_ms += el(8 + 2 * l, 9 + 2 * l);
-      t.refine_ms -= t.lazy_frontend_ms;
-    }
-    t.sort_ms = el(4, 5);
-    t.icp_ms = el(5, 6);
-    t.total_ms = el(0, 6);
-    t.backproject_ms = 0;                 // fused into the per-frame ICP workgroup
-    t.icp_launches = 1;
-    for (int i = 0; i < n_frames; ++i) t.icp_iters_total += results[i].found ? results[i].det.icp.iters : 0;
-    t.scan_algorithmic_bytes = det->scan_bytes_per_frame * n_frames;
-    det->have_times = false;
-  }
+  fl_update_stage_times(det, n_frames, results);
   return FL_OK;
 }
 
@@ -225,7 +254,8 @@ extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uin
   const uint16_t *depth_base = nullptr;
   size_t depth_stride = 0;
   int host_buf = -1;
-  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params, &depth_base, &depth_stride, &host_buf);
+  if (!K || !params) return FL_ERR_INVALID;
+  int rc = stage_and_match(det, n_frames, bgr, depth, mem, K, params->matching_threshold, &depth_base, &depth_stride, &host_buf);
   if (rc) return rc;
   fl_context *ctx = det->ctx;
   det->have_times = false;

@@ -220,6 +220,13 @@ int  fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
 int  fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
                            const uint8_t *const *masks, int mem, float threshold, fl_match *out,
                            int cap, int *n_total);
+/* Detector::match for a batch of frames (the reference is called once per camera frame, linemod.cpp:1356-1441;
+ * test/linemod_recon.cpp:43-80): front-end and match of n_frames frames are queued on the context's stream, the sorted
+ * match lists stay in HBM.  fl_match_batch_collect waits and copies frame `frame`'s list out (same order and
+ * de-duplication as fl_match_frame); fl_export_topk reads them on the device. */
+int  fl_match_batch_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                           int mem, float threshold);
+int  fl_match_batch_collect(fl_detector *det, int frame, fl_match *out, int cap, int *n_total);
 /* similarity + addSimilarities (linemod.cpp:1130-1214,1322-1338) for pyramids [first,first+count)
  * at the coarsest level of the frame last passed to fl_match_*: out = count * (W_T*H_T) u16 (host) */
 int  fl_similarity_maps(fl_detector *det, int first, int count, uint16_t *out);

@@ -346,6 +346,9 @@ def recognition(bgr, depth, K, T_pyramid, bank, threshold=75.0, icp_it_thr=10, d
     arr, keep = _banks([bank])
     t, f, p = keep[0]
     mds = [np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
+    if len(mds) < bank.n_pyramids:        # pyramids without a depth render (bank.py): an empty render, as the product uploads
+        zero = np.zeros((h, w), np.uint16)
+        mds = mds + [zero] * (bank.n_pyramids - len(mds))
     mptr = (C.c_void_p * len(mds))(*[m.ctypes.data for m in mds])
     res = OrcRecognitionResult()
     rc = lib().orc_recognition(_p(b), _p(d), w, h, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
@@ -382,6 +385,9 @@ def recognition_topk(bgr, depth, K, T_pyramid, bank, k, threshold=75.0, icp_it_t
     arr, keep = _banks([bank])
     t, f, p = keep[0]
     mds = [np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
+    if len(mds) < bank.n_pyramids:
+        zero = np.zeros((h, w), np.uint16)
+        mds = mds + [zero] * (bank.n_pyramids - len(mds))
     mptr = (C.c_void_p * len(mds))(*[m.ctypes.data for m in mds])
     res = (OrcRecognitionResult * k)()
     n = lib().orc_recognition_topk(_p(b), _p(d), w, h, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
