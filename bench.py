@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--scenes", type=int, default=8)
     ap.add_argument("--shard", choices=["frames", "templates"], default="frames")
     ap.add_argument("--topk", type=int, default=64, help="records per rank in the template-sharded all-gather")
+    ap.add_argument("--verify-sharded", action="store_true",
+                    help="--shard templates: rank 0 also runs one detector over the whole bank and checks every frame's result bit for bit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra figures of the default line (360 templates, eager front-end, batch sweep, PCIe-inclusive)")

@@ -105,6 +105,8 @@ SIGNATURES = {
     "fl_last_quantized": (_I, [_P, _P]),
     "fl_recognize_batch": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, C.POINTER(Intrinsics),
                                 C.POINTER(RecognitionParams), _P]),
+    "fl_recognize_batch_zoom": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, _I, _I, C.POINTER(Intrinsics),
+                                     C.POINTER(RecognitionParams), _P]),
     "fl_recognize_submit": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, C.POINTER(Intrinsics),
                                  C.POINTER(RecognitionParams)]),
     "fl_recognize_collect": (_I, [_P, _I, _P]),
@@ -114,6 +116,9 @@ SIGNATURES = {
     "fl_nms": (_I, [_P, _I, _F, C.POINTER(_I), C.POINTER(_I)]),
     "fl_export_topk": (_I, [_P, _I, _I, _I, _P]),
     "fl_merge_topk": (_I, [_P, _I, _P, _I]),
+    "fl_export_topk_batch": (_I, [_P, _I, _I, _I, _P]),
+    "fl_merge_topk_batch": (_I, [_P, _I, _I, _I, _P, _I, C.POINTER(_I)]),
+    "fl_refine_matches": (_I, [_P, _I, C.POINTER(C.c_int32), _P, C.POINTER(Intrinsics), C.POINTER(RecognitionParams), _P]),
     "fl_last_stage_times": (_I, [_P, C.POINTER(StageTimes)]),
     "fl_frame_counters": (_I, [_P, _I, C.POINTER(C.c_int32)]),
 }

@@ -363,10 +363,36 @@ class Detector:
     def export_topk(self, frame, k, template_id_base, dev_ptr):
         self.ctx.check(self.lib.fl_export_topk(self.h, frame, k, template_id_base, C.c_void_p(dev_ptr)))
 
+    def export_topk_batch(self, n_frames, k, template_id_base, dev_ptr):
+        self.ctx.check(self.lib.fl_export_topk_batch(self.h, n_frames, k, template_id_base, C.c_void_p(dev_ptr)))
+
+    def refine_matches(self, frames, matches, K, params):
+        """fl_refine_matches: `matches` is a MATCH_DTYPE array with class-local template ids of THIS detector."""
+        n = len(frames)
+        fr = (C.c_int32 * n)(*[int(f) for f in frames])
+        m = np.ascontiguousarray(matches, MATCH_DTYPE)
+        k = L.Intrinsics(self.w0, self.h0, *K)
+        res = (L.RecognitionResult * n)()
+        self.ctx.check(self.lib.fl_refine_matches(self.h, n, fr, _ptr(m), C.byref(k), C.byref(params), res))
+        return res
+
     def close(self):
         if self.h:
             self.lib.fl_detector_destroy(self.h)
             self.h = None
+
+
+def merge_topk_batch(gathered, n_ranks, n_frames, k, cap):
+    """fl_merge_topk_batch: gathered[(rank * n_frames + frame) * k + i] -> (out[n_frames, cap], n_out[n_frames])."""
+    lib = L.load()
+    rec = np.ascontiguousarray(gathered, MATCH_DTYPE)
+    assert rec.size == n_ranks * n_frames * k
+    out = np.zeros((n_frames, cap), MATCH_DTYPE)
+    n_out = (C.c_int * n_frames)()
+    rc = lib.fl_merge_topk_batch(_ptr(rec), n_ranks, n_frames, k, _ptr(out), cap, n_out)
+    if rc < 0:
+        raise FealessError(rc, "fl_merge_topk_batch")
+    return out, np.array(n_out[:], np.int32)
 
 
 def merge_topk(records, cap):

@@ -353,7 +353,8 @@ bool WriteLinemod(const DetectorFile &det, const std::string &filename)
     fprintf(f, " ]\n      pyramid_levels: %d\n      template_pyramids:\n", det.pyramid_levels);
     for (size_t t = 0; t < c.template_pyramids.size(); ++t) {
       fprintf(f, "         -\n            template_id: %zu\n            template_pose: [ ", t);
-      const std::vector<float> &p = c.poses[t];
+      static const std::vector<float> no_pose;
+      const std::vector<float> &p = t < c.poses.size() ? c.poses[t] : no_pose;
       for (size_t i = 0; i < p.size(); ++i) fprintf(f, "%s%.9g%s", i ? ", " : "", p[i], (i % 4 == 3 && i + 1 < p.size()) ? "\n               " : "");
       fprintf(f, " ]\n            templates:\n");
       for (auto &tt : c.template_pyramids[t]) {
@@ -387,12 +388,16 @@ bool ReadPng16(const std::string &filename, std::vector<unsigned short> &pixels,
     std::string type((const char *)&buf[o + 4], 4);
     if (o + 12 + len > buf.size()) return fail("truncated chunk");
     const unsigned char *d = &buf[o + 8];
-    if (type == "IHDR") { w = (int)be32(o + 8); h = (int)be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+    if (type == "IHDR") {
+      if (len != 13) return fail("bad IHDR");
+      w = (int)be32(o + 8); h = (int)be32(o + 12); depth = d[8]; ctype = d[9]; interlace = d[12];
+    }
     else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
     else if (type == "IEND") break;
     o += 12 + len;
   }
   if (w <= 0 || h <= 0 || ctype != 0 || (depth != 16 && depth != 8) || interlace) return fail("unsupported PNG (need non-interlaced 8/16-bit gray)");
+  if ((long long)w * h > (64ll << 20)) return fail("PNG larger than 64 Mpixel");
   const int bpp = depth / 8;
   const size_t stride = (size_t)w * bpp;
   std::vector<unsigned char> raw((stride + 1) * (size_t)h);

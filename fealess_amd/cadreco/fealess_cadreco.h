@@ -133,8 +133,11 @@ bool ReadPng16(const std::string &filename, std::vector<unsigned short> &pixels,
 
 // Extensions of the MI355X build (not in the reference): batch entry point on the same object.
 class CObjRecoLmICPHip;
+// out[i] = what Recognition() puts into vtResult for frame i; frame_rc (optional) = what it would return for frame i.
+// Returns the first non-zero frame code: a frame that fails does not take the others' results with it.
 int CadRecoRecognitionBatch(CObjRecoCAD *handle, int n_frames, const TImageU *rgb, const TImageU16 *depth,
-                            const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out);
+                            const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out,
+                            std::vector<int> *frame_rc = nullptr);
 
 // Opt-in, not in the reference (its Recognition() only ever looks at matches[0]): refine the first k matches of every
 // frame and return the nonMaximumSuppression (ICP/NMS.cpp:6-40, th_obj_dist = nms_dist_mm) winners, best first, in

@@ -52,6 +52,10 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
       return (int)ERROR_OPEN_FILE_FAILED;                                   // numClasses() == 0 (:71-72)
     if (m_det) { fl_detector_destroy(m_det); m_det = nullptr; }
     const int M = (int)df.modalities.size(), L = df.pyramid_levels;
+    // the file is untrusted input: the C ABI reads T[0..L) and one 13-float pose per pyramid
+    if (M < 1 || M > 2 || L < 1 || L > 4 || (int)df.T.size() < L) return (int)ERROR_VERSION_MISMATCH;
+    for (auto &c : df.classes)
+      if (c.poses.size() != c.template_pyramids.size()) return (int)ERROR_VERSION_MISMATCH;
     if (fl_detector_create(m_ctx, M, L, df.T.data(), &m_det) != FL_OK) return (int)ERROR_INVALID_PARAM;
     m_class_ids.clear();
     std::vector<std::vector<unsigned short> > depth_banks;
@@ -101,9 +105,13 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
     return rc;
   }
 
-  int Batch(int n, const TImageU *rgb, const TImageU16 *depth, const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out)
+  // frame_rc (optional): what Recognition() would have returned for each frame; the return value is the first non-zero
+  // of them, and the frames that succeeded keep their results in `out` either way
+  int Batch(int n, const TImageU *rgb, const TImageU16 *depth, const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out,
+            std::vector<int> *frame_rc = nullptr)
   {
     out.clear();
+    if (frame_rc) frame_rc->assign(n > 0 ? n : 0, (int)ERROR_INVALID_PARAM);
     if (!m_ctx || !m_det || n <= 0) return (int)ERROR_INVALID_PARAM;
     // PrepareInputData (:216-259)
     for (int i = 0; i < n; ++i) {
@@ -118,7 +126,10 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
     std::vector<const uint16_t *> dp(n);
     std::vector<std::vector<uint8_t> > zb;
     std::vector<std::vector<uint16_t> > zd;
-    if (K.nWidth != w) {
+    const bool zoom = K.nWidth != w;
+    // the single-hypothesis path zooms on the device (fl_recognize_batch_zoom); only the multi-hypothesis extension still
+    // takes the zoomed frames through host vectors
+    if (zoom && m_topk > 1) {
       zb.resize(n);
       zd.resize(n);
       for (int i = 0; i < n; ++i) {
@@ -133,7 +144,7 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
         dp[i] = zd[i].data();
       }
     } else {
-      for (int i = 0; i < n; ++i) { bp[i] = rgb[i].pData; dp[i] = depth[i].pData; }
+      for (int i = 0; i < n; ++i) { bp[i] = rgb[i].pData; dp[i] = depth[i].pData; }     // zoomed on the device when `zoom`
     }
     if (m_w != w || m_h != h || n > m_batch) {
       if (fl_detector_finalize(m_det, w, h, n > m_batch ? n : m_batch, 0) != FL_OK) {
@@ -160,6 +171,7 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
       for (int i = 0; i < n; ++i) {
         const fl_recognition_result *r = res.data() + (size_t)i * m_topk;
         if (cnt[i] > 0 && r[0].status != FL_OK && r[0].status != FL_ERR_ASSERT) return (int)ERROR_INVALID_PARAM;
+        if (frame_rc) (*frame_rc)[i] = 0;
         int nw = 0;
         if (fl_nms(r, cnt[i], m_nms_dist, win.data(), &nw) != FL_OK) return (int)ERROR_INVALID_PARAM;
         for (int g = 0; g < nw; ++g) {
@@ -174,19 +186,25 @@ class CObjRecoLmICPHip : public CObjRecoCAD {
       return 0;
     }
     std::vector<fl_recognition_result> res(n);
-    if (fl_recognize_batch(m_det, n, bp.data(), dp.data(), FL_MEM_HOST, &k, &m_params, res.data()) != FL_OK) {
+    const int rc = zoom ? fl_recognize_batch_zoom(m_det, n, bp.data(), dp.data(), K.nWidth, K.nHeight, FL_MEM_HOST, &k, &m_params, res.data())
+                        : fl_recognize_batch(m_det, n, bp.data(), dp.data(), FL_MEM_HOST, &k, &m_params, res.data());
+    if (rc != FL_OK) {
       fprintf(stderr, "[fealess_hip] %s\n", fl_last_error(m_ctx));
       return (int)ERROR_INVALID_PARAM;
     }
+    int first_rc = 0;
     for (int i = 0; i < n; ++i) {
-      if (res[i].status != FL_OK) return (int)ERROR_INVALID_PARAM;          // match() returned -1 / ROI assert
+      // match() returned -1 / ROI assert / candidate buffers at a hard cap: that frame fails, the others keep their results
+      const int frc = res[i].status != FL_OK ? (int)ERROR_INVALID_PARAM : 0;
+      if (frame_rc) (*frame_rc)[i] = frc;
+      if (frc) { if (!first_rc) first_rc = frc; continue; }
       if (!res[i].found) continue;                                          // vtResult stays empty, return 0 (:106-109)
       TObjRecoResult r;
       r.strObjTag = m_class_ids[res[i].best.class_idx];                     // cur_match.class_id (:112)
       memcpy(r.tWorld2Cam, res[i].pose, sizeof(r.tWorld2Cam));              // Convert() (:20-30,197)
       out[i].push_back(r);
     }
-    return 0;
+    return first_rc;
   }
 
   fl_recognition_params m_params;
@@ -222,11 +240,11 @@ CObjRecoCAD *CObjRecoCAD::Create(EObjRecoType eType)
 void CObjRecoCAD::Destroy(CObjRecoCAD *pHandle) { delete pHandle; }
 
 int CadRecoRecognitionBatch(CObjRecoCAD *handle, int n_frames, const TImageU *rgb, const TImageU16 *depth,
-                            const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out)
+                            const TCamIntrinsicParam &K, std::vector<std::vector<TObjRecoResult> > &out, std::vector<int> *frame_rc)
 {
   CObjRecoLmICPHip *h = dynamic_cast<CObjRecoLmICPHip *>(handle);
   if (!h) return (int)ERROR_INVALID_PARAM;
-  return h->Batch(n_frames, rgb, depth, K, out);
+  return h->Batch(n_frames, rgb, depth, K, out, frame_rc);
 }
 
 int CadRecoSetMultiHypothesis(CObjRecoCAD *handle, int k, float nms_dist_mm)

@@ -75,15 +75,23 @@ extern "C" int fl_context_create(int device, fl_context **out)
   return FL_OK;
 }
 
-extern "C" void fl_context_destroy(fl_context *ctx)
+// A context outlives the detectors created on it whatever order the caller destroys them in: fl_context_destroy on a
+// context that still has detectors only marks it; the last fl_detector_destroy releases it.
+static void context_release(fl_context *ctx)
 {
-  if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+}
+
+extern "C" void fl_context_destroy(fl_context *ctx)
+{
+  if (!ctx) return;
+  if (ctx->detectors > 0) { ctx->destroy_pending = true; return; }
+  context_release(ctx);
 }
 
 extern "C" const char *fl_last_error(const fl_context *ctx) { return ctx ? ctx->err : "null context"; }
@@ -127,6 +135,7 @@ extern "C" int fl_detector_create(fl_context *ctx, int modalities, int levels, c
     if (T_at_level[l] < 1 || T_at_level[l] > 16) return fl_set_error(ctx, FL_ERR_INVALID, "T out of range");
   fl_detector *det = new fl_detector();
   det->ctx = ctx;
+  ++ctx->detectors;
   det->M = modalities;
   det->L = levels;
   for (int l = 0; l < levels; ++l) det->T[l] = T_at_level[l];
@@ -163,6 +172,8 @@ static void free_device_tables(fl_detector *det)
   det->h_results = nullptr;
   for (auto &e : det->ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (det->d_zoom) { (void)hipFree(det->d_zoom); det->d_zoom = nullptr; }
+  if (det->d_zoom_src) { (void)hipFree(det->d_zoom_src); det->d_zoom_src = nullptr; det->zoom_src_bytes = 0; }
   for (int b = 0; b < 2; ++b) {
     if (det->d_in[b]) { (void)hipFree(det->d_in[b]); det->d_in[b] = nullptr; }
     if (det->ev_up[b]) { (void)hipEventDestroy(det->ev_up[b]); det->ev_up[b] = nullptr; }
@@ -180,7 +191,9 @@ extern "C" void fl_detector_destroy(fl_detector *det)
   free_device_tables(det);
   for (auto &c : det->classes)
     if (c.d_depths) (void)hipFree(c.d_depths);
+  fl_context *ctx = det->ctx;
   delete det;
+  if (--ctx->detectors == 0 && ctx->destroy_pending) context_release(ctx);
 }
 
 extern "C" int fl_detector_add_class(fl_detector *det, const char *class_id, int n_pyramids,
@@ -288,6 +301,76 @@ extern "C" int fl_detector_set_class_filter(fl_detector *det, const char *const 
   return fl_apply_class_filter(det);
 }
 
+// The per-frame workspace (one allocation, frame stride ws_stride) for candidate capacity `cap`; allocates d_ws.
+static int layout_workspace(fl_detector *det, int cap)
+{
+  fl_context *ctx = det->ctx;
+  const int L = det->L, M = det->M, w0 = det->w0, h0 = det->h0;
+  // per-frame workspace layout
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = fl_align(off + bytes, 256); return o; };
+  det->off_bgr = take((size_t)w0 * h0 * 3);
+  det->off_depth = take((size_t)w0 * h0 * 2);
+  for (int l = 0; l < L; ++l) {
+    FlLevelGeom &g = det->geom[l];
+    g.bgr_off = l == 0 ? det->off_bgr : take((size_t)g.w * g.h * 3);
+    for (int m = 0; m < M; ++m) g.quant_off[m] = take((size_t)g.w * g.h);
+    // only the coarsest level is scanned by every template and gets linear memories; the finer
+    // levels are touched by a handful of 16x16 patches per frame and keep just the spread image
+    for (int m = 0; m < M; ++m) {
+      g.lm_off[m] = l == L - 1 ? take((size_t)8 * g.stride + 64) : 0;
+      g.spread_off[m] = l == L - 1 ? 0 : take((size_t)g.w * g.h + 64);
+    }
+  }
+  det->off_tmp = take((size_t)w0 * h0);
+  det->off_count = take(256);
+  det->off_tiles = take((size_t)(L > 1 ? L - 1 : 1) * FL_TILE_BLOCK_WORDS * sizeof(uint32_t));
+  det->lazy_capable = L > 1;
+  for (int l = 0; l + 1 < L; ++l) {
+    const FlLevelGeom &g = det->geom[l];
+    if (((g.w + FL_TILE - 1) / FL_TILE) * ((g.h + FL_TILE - 1) / FL_TILE) > FL_TILE_WORDS * 32) det->lazy_capable = false;
+  }
+  det->off_cand = take((size_t)cap * sizeof(FlCand));
+  det->off_keys = take((size_t)cap * 16);
+  det->off_match = take((size_t)cap * sizeof(fl_match));
+  det->n_pts_max = det->max_tw * det->max_th;
+  det->off_icp = take(fl_icp_ws_bytes(det->n_pts_max));
+  det->ws_stride = fl_align(off, 4096);
+  det->cap = cap;
+  if (const char *pad = getenv("FL_DEV_WS_PAD")) det->ws_stride += fl_align((size_t)atol(pad), 4096);   // dev aid: stride sensitivity
+  if (hipMalloc((void **)&det->d_ws, det->ws_stride * (size_t)det->max_batch) != hipSuccess) {
+    det->d_ws = nullptr;
+    (void)hipGetLastError();
+    return fl_set_error(ctx, FL_ERR_HIP, "frame workspaces: %zu MB for %d frames with %d candidates each", (det->ws_stride * (size_t)det->max_batch) >> 20,
+                        det->max_batch, cap);
+  }
+  FL_HIP(ctx, hipMemset(det->d_ws, 0, det->ws_stride * (size_t)det->max_batch));
+  return FL_OK;
+}
+
+// The reference's candidate / match vectors grow without limit (linemod.cpp:1490-1504, 1575); here they are fixed-size
+// slices of the frame workspace, so a frame that overflows them makes the caller-facing entry points grow the slices
+// (workspace re-laid out for the next power of two >= `needed`) and run the batch again.  Nothing but scratch lives
+// in the workspace between calls.
+int fl_grow_candidates(fl_detector *det, int needed)
+{
+  fl_context *ctx = det->ctx;
+  if (det->cap_hard) return fl_set_error(ctx, FL_ERR_OVERFLOW, "more than %d candidates in one frame (hard cap asked for at fl_detector_finalize)", det->cap);
+  long long want = det->cap;
+  while (want < needed || want <= det->cap) want <<= 1;
+  if (want > (1ll << 28)) return fl_set_error(ctx, FL_ERR_OVERFLOW, "%d candidates in one frame", needed);
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int old_cap = det->cap;
+  (void)hipFree(det->d_ws);
+  det->d_ws = nullptr;
+  int rc = layout_workspace(det, (int)want);
+  if (rc) {                                              // not enough memory: back to the old size, report the overflow
+    if (layout_workspace(det, old_cap)) det->finalized = false;
+    return fl_set_error(ctx, FL_ERR_OVERFLOW, "%d candidates in one frame and no memory for %d frames of that capacity", needed, det->max_batch);
+  }
+  return FL_OK;
+}
+
 extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_batch, int max_candidates)
 {
   if (!det || w0 <= 0 || h0 <= 0 || max_batch <= 0) return FL_ERR_INVALID;
@@ -297,7 +380,11 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   free_device_tables(det);
   det->finalized = false;
   const int L = det->L, M = det->M;
-  int cap = max_candidates > 0 ? max_candidates : 65536;
+  // max_candidates > 0: initial per-frame capacity of the candidate / match buffers, grown on demand (the reference's
+  // vectors are unbounded, linemod.cpp:1490-1504); < 0: a hard cap of -max_candidates (FL_ERR_OVERFLOW beyond it);
+  // 0: 65536, grown on demand
+  int cap = max_candidates > 0 ? max_candidates : (max_candidates < 0 ? -max_candidates : 65536);
+  det->cap_hard = max_candidates < 0;
   int cap2 = 1;
   while (cap2 < cap) cap2 <<= 1;
   cap = cap2;                                        // power of two (bitonic sort)
@@ -439,45 +526,12 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
     det->d_depth_ptrs = tmp;
   }
 
-  // per-frame workspace layout
-  size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off = fl_align(off + bytes, 256); return o; };
-  det->off_bgr = take((size_t)w0 * h0 * 3);
-  det->off_depth = take((size_t)w0 * h0 * 2);
-  for (int l = 0; l < L; ++l) {
-    FlLevelGeom &g = det->geom[l];
-    g.bgr_off = l == 0 ? det->off_bgr : take((size_t)g.w * g.h * 3);
-    for (int m = 0; m < M; ++m) g.quant_off[m] = take((size_t)g.w * g.h);
-    // only the coarsest level is scanned by every template and gets linear memories; the finer
-    // levels are touched by a handful of 16x16 patches per frame and keep just the spread image
-    for (int m = 0; m < M; ++m) {
-      g.lm_off[m] = l == L - 1 ? take((size_t)8 * g.stride + 64) : 0;
-      g.spread_off[m] = l == L - 1 ? 0 : take((size_t)g.w * g.h + 64);
-    }
-  }
-  det->off_tmp = take((size_t)w0 * h0);
-  det->off_count = take(256);
-  det->off_tiles = take((size_t)(L > 1 ? L - 1 : 1) * FL_TILE_BLOCK_WORDS * sizeof(uint32_t));
-  det->lazy_capable = L > 1;
-  for (int l = 0; l + 1 < L; ++l) {
-    const FlLevelGeom &g = det->geom[l];
-    if (((g.w + FL_TILE - 1) / FL_TILE) * ((g.h + FL_TILE - 1) / FL_TILE) > FL_TILE_WORDS * 32) det->lazy_capable = false;
-  }
-  { const char *e = getenv("FL_EAGER_FRONTEND"); det->eager_env = e && *e && *e != '0'; }
-  { const char *e = getenv("FL_DEV_POISON"); det->poison_env = e && *e && *e != '0'; }
-  det->off_cand = take((size_t)cap * sizeof(FlCand));
-  det->off_keys = take((size_t)cap * 16);
-  det->off_match = take((size_t)cap * sizeof(fl_match));
-  det->n_pts_max = det->max_tw * det->max_th;
-  det->off_icp = take(fl_icp_ws_bytes(det->n_pts_max));
-  det->ws_stride = fl_align(off, 4096);
-  if (const char *pad = getenv("FL_DEV_WS_PAD")) det->ws_stride += fl_align((size_t)atol(pad), 4096);   // dev aid: stride sensitivity
   det->w0 = w0;
   det->h0 = h0;
   det->max_batch = max_batch;
-  det->cap = cap;
-  FL_HIP(ctx, hipMalloc((void **)&det->d_ws, det->ws_stride * (size_t)max_batch));
-  FL_HIP(ctx, hipMemset(det->d_ws, 0, det->ws_stride * (size_t)max_batch));
+  { const char *e = getenv("FL_EAGER_FRONTEND"); det->eager_env = e && *e && *e != '0'; }
+  { const char *e = getenv("FL_DEV_POISON"); det->poison_env = e && *e && *e != '0'; }
+  if ((rc = layout_workspace(det, cap))) return rc;
   FL_HIP(ctx, hipMalloc((void **)&det->d_results, sizeof(fl_recognition_result) * (size_t)max_batch));
   FL_HIP(ctx, hipHostMalloc((void **)&det->h_results, sizeof(fl_recognition_result) * (size_t)max_batch,
                             hipHostMallocDefault));

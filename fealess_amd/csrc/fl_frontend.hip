@@ -751,6 +751,16 @@ static int fl_resize_linear(fl_context *ctx, const T *src, int sw, int sh, T *ds
                    });
 }
 
+// device-to-device launchers for the pipeline (fl_recognize_batch_zoom)
+int fl_launch_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+{
+  return fl_resize_linear<uint8_t, 3>(ctx, src, sw, sh, dst, dw, dh, FL_MEM_DEVICE);
+}
+int fl_launch_resize_linear_u16(fl_context *ctx, const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh)
+{
+  return fl_resize_linear<uint16_t, 1>(ctx, src, sw, sh, dst, dw, dh, FL_MEM_DEVICE);
+}
+
 extern "C" int fl_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, int mem)
 {
   return fl_resize_linear<uint8_t, 3>(ctx, src, sw, sh, dst, dw, dh, mem);

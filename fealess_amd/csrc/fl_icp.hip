@@ -137,6 +137,7 @@ struct IcpArgs {
   const float *poses;
   const uint16_t *const *depth_ptrs;
   fl_recognition_result *results;
+  const FlRefineJob *jobs;     // kind 0 with caller-chosen matches (fl_refine_matches): job b refines jobs[b].match on frame jobs[b].frame
 };
 
 // LDS state of one frame workgroup of BS_ threads.  Parity mode: virtual wave 0 chains, the other BS/64 - 1 waves
@@ -1442,7 +1443,8 @@ void k_icp_pipeline(IcpArgs a)
 #ifdef FL_ICP_PHASES
   if (threadIdx.x == 0) S.tkernel = clock64();
 #endif
-  const int job = blockIdx.x, frame = a.job.kind == 0 ? job / a.ranks : job, rank = a.job.kind == 0 ? job % a.ranks : 0;
+  const int job = blockIdx.x, rank = a.job.kind == 0 && !a.jobs ? job % a.ranks : 0;
+  const int frame = a.job.kind == 0 ? (a.jobs ? a.jobs[job].frame : job / a.ranks) : job;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)job * a.ws_stride;
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
@@ -1472,12 +1474,12 @@ void k_icp_pipeline(IcpArgs a)
     if (threadIdx.x == 0) {
       S.status = FL_OK;
       S.g = -1;
-      res->n_matches = counters[1];
+      res->n_matches = a.jobs ? 1 : counters[1];
       res->found = 0;
       res->status = FL_OK;
-      if (counters[2]) S.status = res->status = FL_ERR_OVERFLOW;
-      else if (counters[1] > rank) {
-        const fl_match best = matches[rank];             // matches[0] :111 (rank > 0: multi-hypothesis extension)
+      if (!a.jobs && counters[2]) S.status = res->status = FL_ERR_OVERFLOW;
+      else if (a.jobs || counters[1] > rank) {
+        const fl_match best = a.jobs ? a.jobs[job].match : matches[rank];   // matches[0] :111 (rank > 0: multi-hypothesis extension)
         res->best = best;
         const int g = a.class_first[best.class_idx] + best.template_id;
         const FlPyrInfo pi = a.pyr[g];
@@ -1827,6 +1829,44 @@ int fl_launch_detection_topk(fl_detector *det, int n_frames, int k, const fl_int
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = d_results;
   return icp_launch(ctx, n_frames * k, a);
+}
+
+// refinement of caller-chosen matches (template-sharded recognition: the rank that owns the winning template refines it):
+// job b = (frame, match) read from the device array `jobs`, ICP workspace and result slot b
+int fl_launch_detection_jobs(fl_detector *det, int n_jobs, const FlRefineJob *d_jobs, const fl_intrinsics *K, const fl_recognition_params *p,
+                             const uint16_t *depth, size_t depth_stride)
+{
+  fl_context *ctx = det->ctx;
+  IcpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.ws = det->d_ws + det->off_icp;
+  a.ws_stride = det->ws_stride;
+  a.n_max = det->n_pts_max;
+  a.w = det->w0;
+  a.h = det->h0;
+  a.fx = (float)K->fx;
+  a.fy = (float)K->fy;
+  a.cx = (float)K->cx;
+  a.cy = (float)K->cy;
+  a.it_thr = p->icp_it_thr;
+  a.dmt = p->dist_mean_thr;
+  a.ddt = p->dist_diff_thr;
+  a.mode = p->icp_mode;
+  a.job.kind = 0;
+  a.frame_ws = det->d_ws;
+  a.frame_stride = det->ws_stride;
+  a.ranks = 1;
+  a.scene_base = depth;
+  a.scene_stride = depth_stride;
+  a.off_count = det->off_count;
+  a.off_match = det->off_match;
+  a.pyr = det->d_pyr;
+  a.class_first = det->d_class_first;
+  a.poses = det->d_poses;
+  a.depth_ptrs = det->d_depth_ptrs;
+  a.results = det->d_results;
+  a.jobs = d_jobs;
+  return icp_launch(ctx, n_jobs, a);
 }
 
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *p,

@@ -19,6 +19,8 @@ struct fl_context {
   size_t scratch_bytes = 0;
   void *pinned = nullptr;       // small pinned host buffer for result read-back
   size_t pinned_bytes = 0;
+  int detectors = 0;            // live fl_detector objects on this context
+  bool destroy_pending = false; // fl_context_destroy was called while detectors were alive: the last one releases the context
 };
 
 int fl_set_error(fl_context *ctx, int code, const char *fmt, ...);
@@ -69,6 +71,11 @@ struct FlCand {          // a candidate / match in flight
   float sim;
 };
 
+struct FlRefineJob {     // fl_refine_matches: refine `match` (class-local template id) on frame `frame` of the last batch
+  int32_t frame;
+  fl_match match;
+};
+
 #define FL_TILE 60                 // tile edge in pixels (= CQ_COLS = CQ_CH of k_color_quantize)
 #define FL_TILE_WORDS 16           // bitmap words per frame, level and kind: up to 512 tiles (1280x960: 352)
 // One block of uint32 per frame and fine level: bm[2][FL_TILE_WORDS] (kind 0: tiles whose spread bytes are read,
@@ -105,6 +112,7 @@ struct fl_detector {
   std::vector<FlClass> classes;          // kept sorted by id
   bool finalized = false;
   int w0 = 0, h0 = 0, max_batch = 0, cap = 0;
+  bool cap_hard = false;                 // cap is a hard limit (FL_ERR_OVERFLOW) instead of an initial size that grows
   int n_pyr = 0;
   FlLevelGeom geom[FL_MAX_LEVELS];
 
@@ -145,9 +153,14 @@ struct fl_detector {
   bool read_pending[2] = {false, false};
   int in_flip = 0;
   size_t lazy_bgr_stride = 0;
+  uint8_t *d_zoom = nullptr;             // fl_recognize_batch_zoom: the batch's zoomed frames (max_batch * w0*h0*5 bytes), on first use
+  uint8_t *d_zoom_src = nullptr;         // and the un-zoomed host frames uploaded for it
+  size_t zoom_src_bytes = 0;
   int n_pts_max = 0;
   int last_batch = 0;
   bool last_from_images = false;
+  const uint16_t *last_depth_base = nullptr;   // the last batch's depth frames on the device (fl_refine_matches reads them)
+  size_t last_depth_stride = 0;
   bool last_match_only = false;          // the last batch was fl_match_batch_submit (no ICP stage to time)
 
   // results
@@ -161,6 +174,8 @@ struct fl_detector {
 };
 
 int fl_apply_class_filter(fl_detector *det);
+int fl_grow_candidates(fl_detector *det, int needed);      // re-lays the frame workspaces out for >= needed candidates per frame
+int fl_overflow_needed(fl_detector *det, int n_frames, int *needed);   // after a sync: largest candidate count of an overflowed frame, 0 if none
 void fl_update_stage_times(fl_detector *det, int n_frames, const fl_recognition_result *results);
 
 // ---- stage launchers (defined in the per-domain .hip files) ---------------------------------
@@ -189,11 +204,15 @@ int fl_launch_frontend(fl_detector *det, int n_frames, const uint8_t *bgr, size_
                        const uint16_t *depth, size_t depth_stride, bool allow_lazy);
 int fl_launch_spread_tiles(fl_context *ctx, const uint8_t *quant, size_t quant_stride, uint8_t *spread, size_t spread_stride,
                            int n_frames, int w, int h, int T, const uint32_t *tiles, size_t tiles_stride);
+int fl_launch_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
+int fl_launch_resize_linear_u16(fl_context *ctx, const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh);
 // icp
 size_t fl_icp_ws_bytes(int n_pts_max);
 int fl_launch_detection_topk(fl_detector *det, int n_frames, int k, const fl_intrinsics *K, const fl_recognition_params *p,
                              const uint16_t *depth, size_t depth_stride, uint8_t *ws, fl_recognition_result *d_results);
 size_t fl_icp_ws_bytes(int n_pts_max);
+int fl_launch_detection_jobs(fl_detector *det, int n_jobs, const FlRefineJob *d_jobs, const fl_intrinsics *K, const fl_recognition_params *p,
+                             const uint16_t *depth, size_t depth_stride);
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K,
                               const fl_recognition_params *p, const uint16_t *depth,
                               size_t depth_stride);

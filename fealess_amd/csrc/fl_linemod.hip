@@ -15,6 +15,7 @@
 // with -ffp-contract=off so each operator is one IEEE binary32 operation.
 #include "fl_internal.h"
 #include <limits.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------
 // k_build_lm: one thread per (grid cell, linear position p); the 8 label bytes it produces go
@@ -925,6 +926,30 @@ static int read_matches(fl_detector *det, int frame, fl_match *out, int cap, int
   return FL_OK;
 }
 
+int fl_overflow_needed(fl_detector *det, int n_frames, int *needed)
+{
+  fl_context *ctx = det->ctx;
+  std::vector<int> c((size_t)4 * n_frames);
+  FL_HIP(ctx, hipMemcpy2DAsync(c.data(), 16, det->d_ws + det->off_count, det->ws_stride, 16, n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *needed = 0;
+  for (int f = 0; f < n_frames; ++f)
+    if (c[4 * f + 2] && c[4 * f] > *needed) *needed = c[4 * f];
+  return FL_OK;
+}
+
+// a synchronous entry point's retry policy: on FL_ERR_OVERFLOW grow the candidate buffers to what the frame needs and
+// run the call again (a valid Detector::match input never becomes an error unless the caller asked for a hard cap)
+static bool grow_after_overflow(fl_detector *det, int n_frames, int attempt, int *rc)
+{
+  if (*rc != FL_ERR_OVERFLOW || attempt >= 6) return false;
+  int needed = 0;
+  if (fl_overflow_needed(det, n_frames, &needed) != FL_OK || needed <= 0) return false;
+  const int g = fl_grow_candidates(det, needed);
+  if (g != FL_OK) { *rc = g; return false; }
+  return true;
+}
+
 extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quantized, int mem, float threshold,
                                   fl_match *out, int cap, int *n_total)
 {
@@ -932,19 +957,22 @@ extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quanti
   fl_context *ctx = det->ctx;
   if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
   FL_HIP(ctx, hipSetDevice(ctx->device));
-  for (int l = 0; l < det->L; ++l)
-    for (int m = 0; m < det->M; ++m) {
-      const FlLevelGeom &g = det->geom[l];
-      FL_HIP(ctx, hipMemcpyAsync(det->d_ws + g.quant_off[m], quantized[l * det->M + m], (size_t)g.w * g.h,
-                                 mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    }
-  det->have_times = false;
-  det->lazy = false;                     // every level's quantised image was just supplied
-  int rc = fl_launch_match_core(det, 1, threshold);
-  if (rc) return rc;
-  det->last_batch = 1;
-  det->last_from_images = false;
-  return read_matches(det, 0, out, cap, n_total);
+  for (int attempt = 0;; ++attempt) {
+    for (int l = 0; l < det->L; ++l)
+      for (int m = 0; m < det->M; ++m) {
+        const FlLevelGeom &g = det->geom[l];
+        FL_HIP(ctx, hipMemcpyAsync(det->d_ws + g.quant_off[m], quantized[l * det->M + m], (size_t)g.w * g.h,
+                                   mem == FL_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+      }
+    det->have_times = false;
+    det->lazy = false;                     // every level's quantised image was just supplied
+    int rc = fl_launch_match_core(det, 1, threshold);
+    if (rc) return rc;
+    det->last_batch = 1;
+    det->last_from_images = false;
+    rc = read_matches(det, 0, out, cap, n_total);
+    if (!grow_after_overflow(det, 1, attempt, &rc)) return rc;
+  }
 }
 
 // QuantizedPyramid::quantize with a mask (`angle.copyTo(dst, mask)` linemod.cpp:455-459, `normal.copyTo(dst, mask)`
@@ -965,9 +993,9 @@ __global__ __launch_bounds__(256) void k_apply_mask(uint8_t *__restrict__ quant,
   if (!mask[(size_t)y * w0 + x]) quant[o] = 0;
 }
 
-extern "C" int fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
-                                     const uint8_t *const *masks, int mem, float threshold, fl_match *out, int cap,
-                                     int *n_total)
+static int match_frame_masked_once(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
+                                   const uint8_t *const *masks, int mem, float threshold, fl_match *out, int cap,
+                                   int *n_total)
 {
   if (!det || !bgr || cap < 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
@@ -1016,6 +1044,16 @@ extern "C" int fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const
   return rc;
 }
 
+extern "C" int fl_match_frame_masked(fl_detector *det, const uint8_t *bgr, const uint16_t *depth,
+                                     const uint8_t *const *masks, int mem, float threshold, fl_match *out, int cap,
+                                     int *n_total)
+{
+  for (int attempt = 0;; ++attempt) {
+    int rc = match_frame_masked_once(det, bgr, depth, masks, mem, threshold, out, cap, n_total);
+    if (!det || !grow_after_overflow(det, 1, attempt, &rc)) return rc;
+  }
+}
+
 extern "C" int fl_match_frame(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, float threshold,
                         fl_match *out, int cap, int *n_total)
 {
@@ -1051,12 +1089,17 @@ extern "C" int fl_similarity_maps(fl_detector *det, int first, int count, uint16
   // re-run the scan on frame 0's resident linear memories with the debug tap on; threshold 200%
   // keeps the candidate buffer untouched in practice (counters are reset by the launcher)
   det->have_times = false;
+  // frame 0's counters are saved and restored around the debug scan: its match list (fl_export_topk, fl_frame_counters,
+  // fl_match_batch_collect) stays what the last match left (no candidate survives 200 %, so the list itself is untouched)
+  uint8_t *saved = det->d_ws + det->off_count + 64;
+  FL_HIP(ctx, hipMemcpyAsync(saved, det->d_ws + det->off_count, 16, hipMemcpyDeviceToDevice, ctx->stream));
   FL_HIP(ctx, hipMemsetAsync(det->d_ws + det->off_count, 0, 16, ctx->stream));
   const bool was_lazy = det->lazy;       // no candidate survives 200 %: nothing of the finer levels is needed, and the
   det->lazy = false;                     // batch's colour frames (lazy_bgr) may be gone by now
   rc = launch_scan_refine_sort(det, 1, 200.0f, (uint16_t *)d, first, count);
   det->lazy = was_lazy;
   if (rc) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(det->d_ws + det->off_count, saved, 16, hipMemcpyDeviceToDevice, ctx->stream));
   FL_HIP(ctx, hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return FL_OK;
@@ -1146,6 +1189,34 @@ extern "C" int fl_export_topk(fl_detector *det, int frame, int k, int template_i
   return FL_OK;
 }
 
+__global__ void k_export_topk_batch(const uint8_t *ws, size_t ws_stride, size_t off_count, size_t off_match, int k, int tid_base,
+                                    fl_match *out)
+{
+  const uint8_t *w = ws + (size_t)blockIdx.x * ws_stride;
+  const int n = ((const int *)(w + off_count))[1];
+  const fl_match *m = (const fl_match *)(w + off_match);
+  fl_match *o = out + (size_t)blockIdx.x * k;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    fl_match r;
+    if (i < n) { r = m[i]; r.template_id += tid_base; }
+    else { r.x = r.y = 0; r.similarity = 0.f; r.class_idx = -1; r.template_id = -1; }
+    o[i] = r;
+  }
+}
+
+// the first k matches of each of the last batch's n_frames frames: dev_out[frame * k + i]; one launch
+extern "C" int fl_export_topk_batch(fl_detector *det, int n_frames, int k, int template_id_base, void *dev_out)
+{
+  if (!det || !dev_out || k <= 0 || n_frames <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_export_topk_batch, dim3(n_frames), dim3(64), 0, ctx->stream, det->d_ws, det->ws_stride, det->off_count,
+                     det->off_match, k, template_id_base, (fl_match *)dev_out);
+  FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
 #include <algorithm>
 extern "C" int fl_merge_topk(const fl_match *gathered, int n_records, fl_match *out, int cap)
 {
@@ -1167,4 +1238,20 @@ extern "C" int fl_merge_topk(const fl_match *gathered, int n_records, fl_match *
   int n = (int)std::min<size_t>(v.size(), (size_t)cap);
   for (int i = 0; i < n; ++i) out[i] = v[i];
   return n;
+}
+
+// fl_merge_topk for a whole batch: gathered = what an all-gather of fl_export_topk_batch buffers gives, i.e.
+// gathered[(rank * n_frames + frame) * k + i]; out[frame * cap + j], n_out[frame]
+extern "C" int fl_merge_topk_batch(const fl_match *gathered, int n_ranks, int n_frames, int k, fl_match *out, int cap, int *n_out)
+{
+  if (!gathered || !out || !n_out || n_ranks <= 0 || n_frames <= 0 || k <= 0 || cap <= 0) return FL_ERR_INVALID;
+  std::vector<fl_match> one((size_t)n_ranks * k);
+  for (int f = 0; f < n_frames; ++f) {
+    for (int r = 0; r < n_ranks; ++r)
+      memcpy(&one[(size_t)r * k], gathered + ((size_t)r * n_frames + f) * k, sizeof(fl_match) * (size_t)k);
+    const int n = fl_merge_topk(one.data(), n_ranks * k, out + (size_t)f * cap, cap);
+    if (n < 0) return n;
+    n_out[f] = n;
+  }
+  return FL_OK;
 }

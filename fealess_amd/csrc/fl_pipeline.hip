@@ -101,6 +101,8 @@ static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const 
   if (rc) return rc;
   *depth_base_out = depth_base;
   *depth_stride_out = depth_stride;
+  det->last_depth_base = depth_base;
+  det->last_depth_stride = depth_stride;
   *host_buf_out = host_buf;
   return FL_OK;
 }
@@ -202,14 +204,108 @@ extern "C" int fl_recognize_batch(fl_detector *det, int n_frames, const uint8_t 
                                   const uint16_t *const *depth, int mem, const fl_intrinsics *K,
                                   const fl_recognition_params *params, fl_recognition_result *results)
 {
-  int rc = fl_recognize_submit(det, n_frames, bgr, depth, mem, K, params);
+  // a frame with more coarse candidates than the buffers hold reports FL_ERR_OVERFLOW in its status: grow the buffers to
+  // what it needs and run the batch again, so that no valid input of the reference turns into an error here
+  for (int attempt = 0;; ++attempt) {
+    int rc = fl_recognize_submit(det, n_frames, bgr, depth, mem, K, params);
+    if (rc) return rc;
+    if ((rc = fl_recognize_collect(det, n_frames, results))) return rc;
+    bool over = false;
+    for (int i = 0; i < n_frames; ++i) over = over || results[i].status == FL_ERR_OVERFLOW;
+    if (!over || attempt >= 6) return FL_OK;
+    int needed = 0;
+    if (fl_overflow_needed(det, n_frames, &needed) != FL_OK || needed <= 0) return FL_OK;
+    if (fl_grow_candidates(det, needed) != FL_OK) return FL_OK;      // hard cap / no memory: the per-frame statuses say so
+  }
+}
+
+// PrepareInputData's zoom (obj_reco_lmicp.cpp:229-249: TImage2Mat(..., true) = cv::resize INTER_LINEAR of both images to
+// width 640) followed by Recognition, for a batch, with the zoomed frames staying in HBM: the sw x sh sources (host or
+// device) are resized on the device into a detector-owned buffer and recognised from there.
+extern "C" int fl_recognize_batch_zoom(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                                       int src_w, int src_h, int mem, const fl_intrinsics *K, const fl_recognition_params *params,
+                                       fl_recognition_result *results)
+{
+  if (!det || !bgr || !depth || !K || !params || !results || n_frames <= 0 || src_w <= 0 || src_h <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
+  if (n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames %d > max_batch %d", n_frames, det->max_batch);
+  for (int i = 0; i < n_frames; ++i)
+    if (!bgr[i] || !depth[i]) return fl_set_error(ctx, FL_ERR_INVALID, "frame %d: null pData (CheckTImage)", i);
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  const int w = det->w0, h = det->h0;
+  const size_t zb = fl_align((size_t)w * h * 3, 256), zf = zb + fl_align((size_t)w * h * 2, 256);
+  if (!det->d_zoom) FL_HIP(ctx, hipMalloc((void **)&det->d_zoom, zf * (size_t)det->max_batch));
+  const size_t sb = fl_align((size_t)src_w * src_h * 3, 256), sf = sb + fl_align((size_t)src_w * src_h * 2, 256);
+  if (mem == FL_MEM_HOST && det->zoom_src_bytes < sf * (size_t)n_frames) {
+    FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (det->d_zoom_src) (void)hipFree(det->d_zoom_src);
+    det->d_zoom_src = nullptr;
+    det->zoom_src_bytes = 0;
+    FL_HIP(ctx, hipMalloc((void **)&det->d_zoom_src, sf * (size_t)n_frames));
+    det->zoom_src_bytes = sf * (size_t)n_frames;
+  }
+  std::vector<const uint8_t *> zbp(n_frames);
+  std::vector<const uint16_t *> zdp(n_frames);
+  for (int i = 0; i < n_frames; ++i) {
+    const uint8_t *sbgr = bgr[i];
+    const uint16_t *sdep = depth[i];
+    if (mem == FL_MEM_HOST) {
+      uint8_t *d = det->d_zoom_src + sf * (size_t)i;
+      FL_HIP(ctx, hipMemcpyAsync(d, bgr[i], (size_t)src_w * src_h * 3, hipMemcpyHostToDevice, ctx->stream));
+      FL_HIP(ctx, hipMemcpyAsync(d + sb, depth[i], (size_t)src_w * src_h * 2, hipMemcpyHostToDevice, ctx->stream));
+      sbgr = d;
+      sdep = (const uint16_t *)(d + sb);
+    }
+    uint8_t *z = det->d_zoom + zf * (size_t)i;
+    int rc = fl_launch_resize_linear_bgr8(ctx, sbgr, src_w, src_h, z, w, h);
+    if (rc == FL_OK) rc = fl_launch_resize_linear_u16(ctx, sdep, src_w, src_h, (uint16_t *)(z + zb), w, h);
+    if (rc) return rc;
+    zbp[i] = z;
+    zdp[i] = (const uint16_t *)(z + zb);
+  }
+  return fl_recognize_batch(det, n_frames, zbp.data(), zdp.data(), FL_MEM_DEVICE, K, params, results);
+}
+
+// The refinement half of Recognition() (obj_reco_lmicp.cpp:111-197) for matches the CALLER chose, on frames of the batch
+// last queued with fl_match_batch_submit: template-sharded recognition merges the ranks' top-k lists and then asks the rank
+// that owns the winning template to refine it.  matches[j].template_id is class-local on this detector.
+extern "C" int fl_refine_matches(fl_detector *det, int n_jobs, const int32_t *frames, const fl_match *matches, const fl_intrinsics *K,
+                                 const fl_recognition_params *params, fl_recognition_result *results)
+{
+  if (!det || !frames || !matches || !K || !params || !results || n_jobs <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || det->last_batch < 1 || !det->last_from_images || (det->M == 2 && !det->last_depth_base))
+    return fl_set_error(ctx, FL_ERR_STATE, "fl_match_batch_submit first");
+  if (n_jobs > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_jobs %d > max_batch %d", n_jobs, det->max_batch);
+  if (K->width != det->w0 || K->height != det->h0) return fl_set_error(ctx, FL_ERR_INVALID, "intrinsics size");
+  std::vector<FlRefineJob> jobs((size_t)n_jobs);
+  for (int j = 0; j < n_jobs; ++j) {
+    if (frames[j] < 0 || frames[j] >= det->last_batch) return fl_set_error(ctx, FL_ERR_INVALID, "job %d: frame %d is not in the last batch", j, frames[j]);
+    const fl_match &m = matches[j];
+    if (m.class_idx < 0 || m.class_idx >= (int)det->classes.size() || m.template_id < 0 ||
+        m.template_id >= det->classes[m.class_idx].n_pyramids)
+      return fl_set_error(ctx, FL_ERR_INVALID, "job %d: template %d of class %d is not on this detector", j, m.template_id, m.class_idx);
+    jobs[j].frame = frames[j];
+    jobs[j].match = m;
+  }
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  void *sv = nullptr;
+  int rc = fl_scratch(ctx, sizeof(FlRefineJob) * (size_t)n_jobs, &sv);
   if (rc) return rc;
-  return fl_recognize_collect(det, n_frames, results);
+  FL_HIP(ctx, hipMemcpyAsync(sv, jobs.data(), sizeof(FlRefineJob) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+  FL_HIP(ctx, hipMemsetAsync(det->d_results, 0, sizeof(fl_recognition_result) * (size_t)n_jobs, ctx->stream));
+  det->have_times = false;
+  if ((rc = fl_launch_detection_jobs(det, n_jobs, (const FlRefineJob *)sv, K, params, det->last_depth_base, det->last_depth_stride))) return rc;
+  FL_HIP(ctx, hipMemcpyAsync(det->h_results, det->d_results, sizeof(fl_recognition_result) * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));          // also covers the pageable `jobs` upload
+  memcpy(results, det->h_results, sizeof(fl_recognition_result) * (size_t)n_jobs);
+  return FL_OK;
 }
 
 // Multi-hypothesis recognition of one frame + nonMaximumSuppression (ICP/NMS.cpp, obj_data.h)
-extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, const fl_intrinsics *K,
-                                 const fl_recognition_params *params, int k, fl_recognition_result *results, int *n_results)
+static int recognize_topk_once(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, const fl_intrinsics *K,
+                               const fl_recognition_params *params, int k, fl_recognition_result *results, int *n_results)
 {
   if (!det || !bgr || !depth || !K || !params || !results || !n_results || k < 1 || k > 1024) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
@@ -243,11 +339,30 @@ extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uin
   return FL_OK;
 }
 
+static bool grow_and_retry(fl_detector *det, int n_frames, int attempt, int *rc)
+{
+  if (!det || *rc != FL_ERR_OVERFLOW || attempt >= 6) return false;
+  int needed = 0;
+  if (fl_overflow_needed(det, n_frames, &needed) != FL_OK || needed <= 0) return false;
+  const int g = fl_grow_candidates(det, needed);
+  if (g != FL_OK) { *rc = g; return false; }
+  return true;
+}
+
+extern "C" int fl_recognize_topk(fl_detector *det, const uint8_t *bgr, const uint16_t *depth, int mem, const fl_intrinsics *K,
+                                 const fl_recognition_params *params, int k, fl_recognition_result *results, int *n_results)
+{
+  for (int attempt = 0;; ++attempt) {
+    int rc = recognize_topk_once(det, bgr, depth, mem, K, params, k, results, n_results);
+    if (!grow_and_retry(det, 1, attempt, &rc)) return rc;
+  }
+}
+
 // The same for a whole batch: n_frames * k ICP workgroups in one launch.  results[f * k + r] is hypothesis r of frame f,
 // n_results[f] = min(k, matches of frame f).
-extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
-                                       int mem, const fl_intrinsics *K, const fl_recognition_params *params, int k,
-                                       fl_recognition_result *results, int *n_results)
+static int recognize_batch_topk_once(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                                     int mem, const fl_intrinsics *K, const fl_recognition_params *params, int k,
+                                     fl_recognition_result *results, int *n_results)
 {
   if (!results || !n_results || k < 1 || k > 1024) return FL_ERR_INVALID;
   if (det && det->M != 2) return fl_set_error(det->ctx, FL_ERR_INVALID, "needs the colour + depth modalities");
@@ -280,6 +395,16 @@ extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uin
     n_results[f] = n < 0 ? 0 : n;
   }
   return FL_OK;
+}
+
+extern "C" int fl_recognize_batch_topk(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                                       int mem, const fl_intrinsics *K, const fl_recognition_params *params, int k,
+                                       fl_recognition_result *results, int *n_results)
+{
+  for (int attempt = 0;; ++attempt) {
+    int rc = recognize_batch_topk_once(det, n_frames, bgr, depth, mem, K, params, k, results, n_results);
+    if (!grow_and_retry(det, n_frames, attempt, &rc)) return rc;
+  }
 }
 
 // nonMaximumSuppression (ICP/NMS.cpp:6-40) over refined hypotheses, in list order.  winners[g] = index of the

@@ -10,7 +10,10 @@ independent ways:
   records (k * 20 bytes, latency-bound), after which every rank merges them exactly as one
   Detector::match over the whole bank would order them (std::sort + std::unique,
   linemod.cpp:1437-1439).  Contiguous slices keep template ids ordered across ranks, which is what
-  makes "local sort/unique, then merge" equal to the global result.
+  makes "local sort/unique, then merge" equal to the global result.  Recognition() then refines
+  matches[0] (obj_reco_lmicp.cpp:111-197): the rank whose slice holds that template does it (the
+  depth renders are sharded with the templates) and the poses are summed over the ranks
+  (`template_sharded_recognize`).
 """
 import numpy as np
 
@@ -69,3 +72,44 @@ def template_sharded_match(det, ctx, bgr, depth, threshold, k, template_id_base,
     ctx.synchronize()
     gathered = allgather_records(buf, dist)
     return merge_topk(gathered, k)
+
+
+def owner_of(template_id, n_templates, world):
+    """Rank whose contiguous slice (shard_range) holds global template id `template_id`."""
+    for r in range(world):
+        first, count = shard_range(n_templates, world, r)
+        if first <= template_id < first + count:
+            return r
+    raise ValueError(f"template {template_id} outside 0..{n_templates}")
+
+
+def template_sharded_recognize(n_frames, k, n_templates, world, rank, local_topk, allgather, refine, allreduce_sum):
+    """Recognition() of n_frames frames against a bank sharded over `world` ranks -- the host logic, with the device work
+    behind four callables so that the CPU tests (gloo + oracle) and the GPU path (RCCL + HIP detector) run the same code:
+
+      local_topk()            -> this rank's records of all frames, MATCH_DTYPE [n_frames, k] with GLOBAL template ids,
+                                 padded with template_id = -1 (numpy), or a uint8 device tensor of the same bytes
+      allgather(local)        -> numpy MATCH_DTYPE [world, n_frames, k]
+      refine(frames, matches) -> [n_jobs, 17] float32: found flag + row-major 4x4 pose, for the frames whose winning template
+                                 this rank owns (`matches` carry class-local ids of this rank's shard)
+      allreduce_sum(array)    -> the elementwise sum over ranks of a float32 numpy array (every rank gets it)
+
+    Returns (merged first matches MATCH_DTYPE [n_frames] with global ids and template_id = -1 where nothing matched,
+             n_matches per frame (capped at k), poses float32 [n_frames, 17])."""
+    from .api import merge_topk_batch
+    first, _count = shard_range(n_templates, world, rank)
+    gathered = allgather(local_topk())
+    merged, n_out = merge_topk_batch(np.ascontiguousarray(gathered).reshape(-1), world, n_frames, k, k)
+    best = np.zeros(n_frames, MATCH_DTYPE)
+    best["template_id"] = -1
+    has = n_out > 0
+    best[has] = merged[has, 0]
+    # one global std::sort + unique, then matches[0] (linemod.cpp:1437-1439, obj_reco_lmicp.cpp:111): its owner refines it
+    mine = [f for f in range(n_frames) if has[f] and owner_of(int(best["template_id"][f]), n_templates, world) == rank]
+    poses = np.zeros((n_frames, 17), np.float32)
+    if mine:
+        jobs = best[mine].copy()
+        jobs["template_id"] -= first
+        out = refine(mine, jobs)
+        poses[mine] = out
+    return best, n_out, allreduce_sum(poses)

@@ -274,7 +274,6 @@ def recognition_scene(quantize_fn, levels=2, w=640, h=480, seed=0, n_views=6, n_
         tl, p13, d01 = out
         bank.add_pyramid(tl, p13, d01)
         k += 1
-    zero_depth = np.zeros((h, w), np.uint16)
-    for _ in range(n_random):
-        bank.add_pyramid(random_pyramid(rng, levels, M, w, h), None, zero_depth)
+    for _ in range(n_random):              # no depth render (bank.py: pyramids without one come last)
+        bank.add_pyramid(random_pyramid(rng, levels, M, w, h), None, None)
     return dict(bgr=bgr, depth=depth, bank=bank, K=(FX, FY, CX, CY), R_true=R_true, t_true=t_true)

@@ -121,7 +121,7 @@ typedef struct {
 /* ---- context ---------------------------------------------------------------------------- */
 int  fl_abi_version(void);
 int  fl_context_create(int device, fl_context **out);
-void fl_context_destroy(fl_context *ctx);
+void fl_context_destroy(fl_context *ctx);   /* with detectors still alive: deferred until the last fl_detector_destroy */
 const char *fl_last_error(const fl_context *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL restores the context's own */
 int  fl_context_set_stream(fl_context *ctx, void *hip_stream);
@@ -149,10 +149,20 @@ int  fl_detector_set_model_depths(fl_detector *det, int class_idx, int first, in
  * flattened feature tables and allocates every per-frame workspace in HBM.  max_candidates is
  * the per-frame capacity of the candidate / match buffers (0 = default 65536). */
 int  fl_detector_finalize(fl_detector *det, int w0, int h0, int max_batch, int max_candidates);
+/* max_candidates: per-frame capacity of the coarse-candidate / match buffers.  > 0 (or 0 = 65536): an INITIAL size -- a frame
+ * that needs more makes the synchronous entry points (fl_match_quantized / _frame / _frame_masked, fl_recognize_batch /
+ * _batch_zoom / _topk / _batch_topk) grow the buffers and run again, because the reference's vectors are unbounded
+ * (linemod.cpp:1490-1504, 1575); the queued ones (fl_recognize_submit / fl_match_batch_submit) cannot replay a batch and
+ * report FL_ERR_OVERFLOW in that frame's status (the other frames keep their results).  < 0: a hard cap of
+ * -max_candidates, FL_ERR_OVERFLOW beyond it. */
 /* Detector::match's `class_ids` argument (linemod.hpp:319-327, linemod.cpp:1418-1434): n = 0 matches every
  * class (the default, and what Recognition passes); otherwise only the listed classes that exist.
  * Sticky until changed; may be called before or after fl_detector_finalize. */
 int  fl_detector_set_class_filter(fl_detector *det, const char *const *class_ids, int n);
+/* class_ids is treated as a SET.  The reference calls matchClass once per listed id, duplicates included
+ * (linemod.cpp:1427-1433), and then relies on std::sort + adjacent std::unique (:1437-1439) to drop the repeated matches;
+ * whether every repeat ends up adjacent is up to the (unstable) sort, so the duplicate-free list is one of its valid
+ * outcomes -- the one returned here.  Unknown ids match nothing (:1429-1431). */
 int  fl_detector_num_templates(const fl_detector *det);     /* Detector::numTemplates() :1652 */
 int  fl_detector_num_classes(const fl_detector *det);
 
@@ -242,6 +252,12 @@ int  fl_last_quantized(fl_detector *det, uint8_t *out);
 int  fl_recognize_batch(fl_detector *det, int n_frames, const uint8_t *const *bgr,
                         const uint16_t *const *depth, int mem, const fl_intrinsics *K,
                         const fl_recognition_params *params, fl_recognition_result *results);
+/* PrepareInputData's zoom + Recognition (obj_reco_lmicp.cpp:229-249, 39-45): n_frames frames of src_w x src_h are
+ * resized (cv::resize INTER_LINEAR semantics, as fl_resize_linear_*) to the detector's w0 x h0 on the device and
+ * recognised from HBM without a host round trip.  K is passed through as the reference passes it. */
+int  fl_recognize_batch_zoom(fl_detector *det, int n_frames, const uint8_t *const *bgr, const uint16_t *const *depth,
+                             int src_w, int src_h, int mem, const fl_intrinsics *K, const fl_recognition_params *params,
+                             fl_recognition_result *results);
 /* same, but only queues the work on the context's stream; fl_recognize_collect() waits and
  * copies the results out.  Lets the caller overlap two contexts / batches. */
 int  fl_recognize_submit(fl_detector *det, int n_frames, const uint8_t *const *bgr,
@@ -269,9 +285,22 @@ int  fl_nms(const fl_recognition_result *objs, int n, float th_obj_dist, int *wi
  * all-gather by the caller; template ids are offset by template_id_base (the shard's first
  * global id).  Queued on the context's stream, no synchronisation. */
 int  fl_export_topk(fl_detector *det, int frame, int k, int template_id_base, void *dev_out);
+/* the same for every frame of the last batch in one launch: dev_out[frame * k + i] */
+int  fl_export_topk_batch(fl_detector *det, int n_frames, int k, int template_id_base, void *dev_out);
 /* merge n_ranks*k gathered records (host) exactly as one Detector::match over the union would
  * order them; returns the number written to out (<= cap). */
 int  fl_merge_topk(const fl_match *gathered, int n_records, fl_match *out, int cap);
+
+/* fl_merge_topk per frame of a batch: gathered[(rank * n_frames + frame) * k + i] is what an all-gather of the ranks'
+ * fl_export_topk_batch buffers yields; out[frame * cap + j], n_out[frame] (all host memory) */
+int  fl_merge_topk_batch(const fl_match *gathered, int n_ranks, int n_frames, int k, fl_match *out, int cap, int *n_out);
+/* Template-sharded recognition (BASELINE configs[3]): after the merge, the rank that owns frame f's winning template
+ * refines it -- the second half of Recognition() (obj_reco_lmicp.cpp:111-197: crop rectangles from the template, the
+ * depth render, detection(), pose) for a match chosen by the caller instead of this detector's own matches[0].
+ * frames[j] indexes the batch last queued with fl_match_batch_submit (whose depth frames must still be where they were),
+ * matches[j].template_id is class-local on THIS detector; results[j] (host) as fl_recognize_batch fills them. */
+int  fl_refine_matches(fl_detector *det, int n_jobs, const int32_t *frames, const fl_match *matches, const fl_intrinsics *K,
+                       const fl_recognition_params *params, fl_recognition_result *results);
 
 /* diagnostics: per-frame counters of the last match {coarse candidates, matches after sort/unique,
  * overflow flag, 0} (host memory) */

@@ -140,6 +140,49 @@ def test_png16_reader(tmp_path):
                                   C.byref(w), C.byref(h)) == -1
 
 
+def test_png16_reader_rejects_malformed_files(tmp_path):
+    """The depth renders are file input: a short IHDR at the end of the file, a truncated chunk, a truncated IDAT stream and
+    an absurd size must be refused, not read out of bounds."""
+    lib = _cad()
+    img = np.arange(20 * 30, dtype=np.uint16).reshape(20, 30)
+    good = str(tmp_path / "g.png")
+    write_png16(good, img)
+    data = open(good, "rb").read()
+    out = np.zeros(img.size, np.uint16)
+    w, h = C.c_int(0), C.c_int(0)
+
+    def read(blob):
+        p = str(tmp_path / "x.png")
+        open(p, "wb").write(blob)
+        return lib.cadreco_read_png16(p.encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(w), C.byref(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    assert read(data) == 0
+    assert read(data[:8] + chunk(b"IHDR", b"\x00\x00\x00\x1e\x00\x00")) == -1          # IHDR of 6 bytes as the last chunk
+    assert read(data[:40]) == -1                                                        # chunk cut short
+    assert read(data[:-30] + data[-12:]) == -1                                          # IDAT stream does not inflate to w*h
+    huge = chunk(b"IHDR", struct.pack(">IIBBBBB", 1 << 20, 1 << 20, 16, 0, 0, 0, 0))
+    assert read(data[:8] + huge + data[8 + 25:]) == -1                                  # 2^40 pixels
+
+
+def test_addobj_rejects_inconsistent_bank_files(tmp_path):
+    """AddObj hands T[0..levels) and one pose per pyramid to the C ABI: a file whose T is shorter than pyramid_levels must be
+    refused before that (no GPU needed: the check precedes any device work; without a device AddObj fails anyway)."""
+    from fealess_amd import synth
+    lib = _cad()
+    lib.cadreco_create.restype = C.c_void_p
+    bank = synth.make_bank("obj", 3, 2, 2, 640, 480, seed=3)
+    d = tmp_path / "bank"
+    d.mkdir()
+    write_linemod_yaml(str(d / "linemod_templates.yml"), bank, [5])          # T has 1 entry, pyramid_levels says 2
+    h = lib.cadreco_create(1)
+    assert h
+    rc = lib.cadreco_add_obj(C.c_void_p(h), str(d).encode())
+    assert rc != 0
+    lib.cadreco_destroy(C.c_void_p(h))
+
+
 def test_linemod_yaml_reader(tmp_path):
     from fealess_amd import synth
     lib = _cad()

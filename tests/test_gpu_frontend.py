@@ -131,3 +131,48 @@ def test_resize_linear_bit_exact(ctx, oracle, sw, sh, dw, dh):
     depth = rng.integers(0, 65536, (sh, sw)).astype(np.uint16)
     assert np.array_equal(ctx.resize_linear(bgr, dw, dh), oracle.resize_linear_u8(bgr, dw, dh))
     assert np.array_equal(ctx.resize_linear(depth, dw, dh), oracle.resize_linear_u16(depth, dw, dh))
+
+
+def test_c3_match_from_images_1280x720_three_levels(ctx, oracle):
+    """BASELINE configs[2] geometry end to end: Detector::match from BGR + depth at 1280x720 with T = {5, 8, 4}
+    (linemod.cpp:1356-1441), single-frame entry and the batched one, against orc_match_images."""
+    from fealess_amd.bank import TemplateBank
+    w, h, T = 1280, 720, [5, 8, 4]
+    K = (915.0, 915.0, 640.0, 360.0)
+    rng = np.random.default_rng(3)
+    R, t = synth.object_pose(tx=30.0, ty=-20.0, tz=660.0)
+    frames = []
+    bank = TemplateBank("obj", 3, 2)
+    for s in range(2):
+        Rs = synth.rot_z(0.05 * s) @ R
+        depth, bgr, _ = synth.render(w, h, Rs, t + np.array([25.0 * s, 0, 0]), seed=40 + s, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+        frames.append((bgr, depth))
+        for v in range(2):
+            dR = synth.rot_z(np.deg2rad(rng.uniform(-2, 2))) @ synth.rot_x(np.deg2rad(rng.uniform(-2, 2)))
+            tv = t + np.array([25.0 * s, 0, 0]) + rng.uniform(-10, 10, 3)
+            d_bg, bgr_v, mask = synth.render(w, h, dR @ Rs, tv, seed=60 + 2 * s + v, noise=False, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+            ex = ctx.extract_template_pyramid(bgr_v, d_bg, (mask * 255).astype(np.uint8), 3)
+            assert ex is not None
+            bank.add_pyramid(ex[0], synth.pose13(dR @ Rs, tv), None)
+    while bank.n_pyramids < 40:
+        bank.add_pyramid(synth.random_pyramid(rng, 3, 2, w, h), None, None)
+    det = api.Detector(ctx, 2, T)
+    det.add_class(bank)
+    det.finalize(w, h, max_batch=2)
+    thr = 65.0
+    exps = [oracle.match_images(b, d, T, [bank], thr) for b, d in frames]
+    assert all(n > 0 for _, n in exps)
+    for (b, d), (exp, n_exp) in zip(frames, exps):
+        got, n_got = det.match(b, d, thr)
+        for a, e in zip(det.last_quantized(), oracle.quantize_pyramid(b, d, 3)):
+            assert np.array_equal(a, e)
+        assert n_got == n_exp and got.tobytes() == exp[:len(got)].tobytes()
+    # the batched entry (lazy fine levels) gives the same lists
+    both = det.match_batch([f[0] for f in frames], [f[1] for f in frames], thr)
+    for (got, n_got), (exp, n_exp) in zip(both, exps):
+        assert n_got == n_exp and got.tobytes() == exp[:len(got)].tobytes()
+    # fl_similarity_maps is a debug tap: the match lists of the batch survive it
+    det.similarity_maps(0, 4)
+    again, n_again = det.match_batch_collect(0)
+    assert n_again == exps[0][1] and again.tobytes() == exps[0][0][:len(again)].tobytes()
+    det.close()

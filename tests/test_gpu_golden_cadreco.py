@@ -129,6 +129,23 @@ def test_cadreco_facade_end_to_end(tmp_path, oracle):
     assert lib.cadreco_set_params(h, 75.0, 10, 0.5, 0.01, 0) == 0
     assert reco() == 0 and n.value == 1 and np.abs(pose.reshape(4, 4) - exp["pose"]).max() <= 1e-4
     lib.cadreco_destroy(h)
+    # the same through a C++ caller that holds a CObjRecoCAD* (virtual calls, std::string / std::vector across the boundary)
+    import subprocess
+    cad = os.path.join(ROOT, "fealess_amd", "cadreco")
+    exe = str(tmp_path / "caller")
+    r = subprocess.run(["g++", "-std=c++14", "-O1", "-I", cad, os.path.join(ROOT, "tests", "dropin", "tu_caller_gpu.cpp"), "-o", exe,
+                        "-L", cad, "-lcadreco_hip", "-Wl,-rpath," + cad, "-Wl,-rpath," + os.path.join(ROOT, "fealess_amd", "csrc")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    bgr.tofile(str(tmp_path / "f.bgr"))
+    depth.tofile(str(tmp_path / "f.d16"))
+    r = subprocess.run([exe, str(d), str(tmp_path / "f.bgr"), str(tmp_path / "f.d16"), "640", "480", repr(fx), repr(fy), repr(cx), repr(cy)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines() if " " in l)
+    assert lines["addobj"] == "0" and lines["recognition"] == "0 1" and lines["tag"] == "obj"
+    cpose = np.array([float(v) for v in lines["pose"].split()], np.float32).reshape(4, 4)
+    assert np.array_equal(cpose, np.asarray(exp["pose"], np.float32)) or np.abs(cpose - exp["pose"]).max() <= 1e-4
 
 
 def test_template_sharded_topk_on_one_gpu(ctx, oracle):
@@ -157,3 +174,31 @@ def test_template_sharded_topk_on_one_gpu(ctx, oracle):
     full, n_full = oracle.match_quantized(qs, w0, h0, T, [bank], 70.0)
     assert n_full > 4 and len(merged) == min(k, n_full)
     assert merged.tobytes() == full[:len(merged)].tobytes()
+
+
+def test_template_sharded_recognition_two_ranks_on_one_gpu(tmp_path):
+    """BASELINE configs[3] rehearsed on one GPU: two processes, each holding half of the bank, gloo in place of RCCL
+    (two RCCL ranks cannot share a device), `bench.py --shard templates --verify-sharded`: every frame's best match and
+    pose must equal, bit for bit, what one detector over the whole bank returns from fl_recognize_batch."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "templates", "--share-device",
+           "--verify-sharded", "--templates", "30", "--batch", "6", "--scenes", "3", "--steps", "1", "--warmup", "0", "--icp-iters", "8",
+           "--topk", "16"]
+    env = dict(os.environ)
+    env.pop("FL_DEV_POISON", None)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["templates_total"] == 60
+    assert out["verified_against_single_detector"] is True, out
+    assert out["detections"] == "6/6"
+    assert out["collectives"]["ranks"] == 2

@@ -423,3 +423,54 @@ def test_device_frames_in_place_and_gathered_equal_host_frames(ctx, oracle):
     for h, a, t in zip(host, again, third[::-1]):
         assert np.array_equal(_bits(a["pose"]), _bits(h["pose"])) and np.array_equal(_bits(t["pose"]), _bits(h["pose"]))
     det.close()
+
+
+def test_recognition_grows_the_candidate_buffers(ctx, oracle):
+    """A cluttered frame (threshold low enough for thousands of coarse candidates) overflows an initial capacity of 256:
+    the synchronous recognition entry points grow the buffers and run again, every frame of the batch keeps the
+    oracle's result (the reference's vectors are unbounded, linemod.cpp:1490-1504)."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=5, n_views=4, n_random=20)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480, max_batch=2, max_candidates=256)
+    thr = -100.0                               # raw threshold 0: every non-zero coarse cell of every template is a candidate
+    got = det.recognize_batch([sc["bgr"], sc["bgr"]], [sc["depth"], sc["depth"]], sc["K"], thr, 6, 0.0, -3.0e38)
+    exp = oracle.recognition(sc["bgr"], sc["depth"], sc["K"], [5, 8], sc["bank"], thr, 6, 0.0, -3.0e38)
+    assert exp["n_matches"] > 256
+    for g in got:
+        assert g["status"] == 0 and g["found"] == exp["found"] == 1
+        assert g["n_matches"] == exp["n_matches"]
+        assert g["best"]["template_id"] == exp["best"]["template_id"] and g["best"]["similarity"] == exp["best"]["similarity"]
+        assert np.array_equal(_bits(g["pose"]), _bits(exp["pose"]))
+    det.close()
+
+
+def test_recognition_with_2000_pyramids_matches_oracle(ctx, oracle):
+    """The north_star shape's bank size: Recognition() of a few frames against a 2000-pyramid bank (rendered views + random
+    pyramids) equals the oracle's, bit for bit (linemod.cpp:1458: the N-template loop is what the target is sized on)."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=21, n_views=4, n_random=1996)
+    assert sc["bank"].n_pyramids == 2000
+    frames_b = [sc["bgr"], np.roll(sc["bgr"], 6, axis=1), np.roll(sc["bgr"], -10, axis=1)]
+    frames_d = [sc["depth"], np.roll(sc["depth"], 6, axis=1), np.roll(sc["depth"], -10, axis=1)]
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480, max_batch=3)
+    got = det.recognize_batch(frames_b, frames_d, sc["K"], 75.0, 10, 0.5, 0.01)
+    for g, b, d in zip(got, frames_b, frames_d):
+        e = oracle.recognition(b, d, sc["K"], [5, 8], sc["bank"], 75.0, 10, 0.5, 0.01)
+        assert g["status"] == 0 and g["found"] == e["found"] == 1 and g["n_matches"] == e["n_matches"]
+        assert g["best"]["template_id"] == e["best"]["template_id"] and g["best"]["x"] == e["best"]["x"] and g["best"]["y"] == e["best"]["y"]
+        assert g["best"]["similarity"] == e["best"]["similarity"]
+        assert g["det"]["n_points"] == e["det"]["n_points"] and g["det"]["icp"]["iters"] == e["det"]["icp"]["iters"]
+        assert np.array_equal(_bits(g["pose"]), _bits(e["pose"]))
+    det.close()
+
+
+def test_context_outlives_its_detectors_in_either_destroy_order():
+    """fl_context_destroy before fl_detector_destroy used to free the stream the detector still synchronises on."""
+    c = api.Context(0)
+    det = api.Detector(c, 2, [5, 8])
+    det.add_class(synth.make_bank("obj", 4, 2, 2, 640, 480, seed=1))
+    det.finalize(640, 480)
+    c.close()                # deferred: the detector is still alive
+    det.close()              # releases the context

@@ -163,14 +163,29 @@ def test_empty_bank_and_no_match(ctx, oracle):
     det.close()
 
 
-def test_candidate_overflow_is_reported(ctx):
+def test_candidate_buffers_grow_like_the_reference_vectors(ctx, oracle):
+    """The reference's candidate / match vectors are unbounded (linemod.cpp:1490-1504, 1575): a threshold low enough to
+    make every non-zero cell a candidate overflows an initial capacity of 64 many times over, and the result must still be
+    the oracle's list.  A caller that asks for a hard cap (negative max_candidates) gets FL_ERR_OVERFLOW instead."""
     rng = np.random.default_rng(4)
     qs = _quant_pyramid(rng, 320, 240, 1, 1, density=0.9)
+    bank = synth.make_bank("obj", 40, 1, 1, 320, 240, seed=9, bbox=64)
     det = api.Detector(ctx, 1, [8])
-    det.add_class(synth.make_bank("obj", 40, 1, 1, 320, 240, seed=9, bbox=64))
+    det.add_class(bank)
     det.finalize(320, 240, max_batch=1, max_candidates=64)
+    got, n = det.match_quantized(qs, -100.0, cap=1 << 17)       # raw_threshold 0: every non-zero cell is a candidate
+    exp, n_exp = oracle.match_quantized(qs, 320, 240, [8], det.banks, -100.0)
+    assert n == n_exp > 20000
+    _assert_matches_equal(got, exp)
+    # the grown buffers stay: a second call needs no retry and gives the same list
+    got2, n2 = det.match_quantized(qs, -100.0, cap=1 << 17)
+    assert n2 == n and np.array_equal(got2, got)
+    det.close()
+    det = api.Detector(ctx, 1, [8])
+    det.add_class(bank)
+    det.finalize(320, 240, max_batch=1, max_candidates=-64)
     with pytest.raises(api.FealessError) as e:
-        det.match_quantized(qs, -100.0)       # raw_threshold 0: every non-zero cell is a candidate
+        det.match_quantized(qs, -100.0)
     assert e.value.code == -4
     det.close()
 

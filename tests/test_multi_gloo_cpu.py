@@ -65,6 +65,78 @@ def test_template_sharded_allgather_merge_equals_global(tmp_path, k):
         assert ok == "1", (r, n_m, n_full)
 
 
+def _worker_recognize(rank, world, port, out_dir):
+    """template_sharded_recognize (the host logic bench.py --shard templates runs with RCCL + the HIP detector) with gloo and the
+    oracle behind its four callables: per-rank match of the slice, all-gather, merge, refinement by the owner, pose sum."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle_py as O
+    from fealess_amd import synth
+    from fealess_amd import distributed as D
+    from fealess_amd.bank import MATCH_DTYPE
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, thr, k = [5, 8], 70.0, 16
+    sc = synth.recognition_scene(lambda b, d, l: O.quantize_pyramid(b, d, l), levels=2, seed=13, n_views=5, n_random=6)
+    bank, K = sc["bank"], sc["K"]
+    # frame 1: the same scene shifted sideways
+    frames = [(sc["bgr"], sc["depth"]), (np.roll(sc["bgr"], 14, axis=1), np.roll(sc["depth"], 14, axis=1))]
+    n = bank.n_pyramids
+    shard, first = D.shard_bank(bank, world, rank)
+
+    def local_topk():
+        out = np.zeros((len(frames), k), MATCH_DTYPE)
+        for f, (b, d) in enumerate(frames):
+            m, _ = O.match_images(b, d, T, [shard], thr)
+            out[f] = D.pad_topk(m, k, first)
+        return out
+
+    def allgather(local):
+        return D.allgather_records(local.reshape(-1), dist).reshape(world, len(frames), k)
+
+    def refine(fr, matches):
+        out = np.zeros((len(fr), 17), np.float32)
+        for j, f in enumerate(fr):
+            r = O.recognition(frames[f][0], frames[f][1], K, T, shard, thr, 8, 0.0, -3.0e38)
+            # the global winner is its owner's local matches[0]
+            assert r["best"]["template_id"] == int(matches["template_id"][j]) and r["best"]["x"] == int(matches["x"][j])
+            out[j, 0] = r["found"]
+            out[j, 1:] = r["pose"].reshape(-1)
+        return out
+
+    def allreduce_sum(a):
+        t = torch.from_numpy(a.copy())
+        dist.all_reduce(t)
+        return t.numpy()
+
+    best, n_out, poses = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk, allgather, refine, allreduce_sum)
+    ok = True
+    owners = []
+    for f, (b, d) in enumerate(frames):
+        e = O.recognition(b, d, K, T, bank, thr, 8, 0.0, -3.0e38)
+        ok = ok and e["found"] == 1 and poses[f, 0] == 1.0
+        ok = ok and int(best["template_id"][f]) == e["best"]["template_id"] and np.float32(best["similarity"][f]) == e["best"]["similarity"]
+        ok = ok and np.array_equal(poses[f, 1:].view(np.uint32), e["pose"].reshape(-1).astype(np.float32).view(np.uint32))
+        ok = ok and n_out[f] == min(k, e["n_matches"])
+        owners.append(D.owner_of(int(best["template_id"][f]), n, world))
+    with open(os.path.join(out_dir, f"reco{rank}.txt"), "w") as fh:
+        fh.write(f"{int(ok)} {owners}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_template_sharded_recognition_with_icp_handoff(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker_recognize, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok = open(tmp_path / f"reco{r}.txt").read().split()[0]
+        assert ok == "1", open(tmp_path / f"reco{r}.txt").read()
+
+
 def test_shard_range_properties():
     sys.path.insert(0, ROOT)
     from fealess_amd.distributed import shard_range
