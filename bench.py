@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--templates", type=int, default=2000)
     ap.add_argument("--levels", type=int, default=0, help="pyramid levels (default: 2 for c2, 3 for c3)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per step per GPU (default 1280 for c2 = 5 ICP workgroups on each of the 256 CUs; 256 for c3)")
+                    help="frames per step per GPU (default 2048 for c2 = two rounds of 4 ICP workgroups on each of the 256 CUs; 256 for c3)")
     ap.add_argument("--icp-iters", type=int, default=20)
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=8)
@@ -74,7 +74,7 @@ def parse():
     if a.levels == 0:
         a.levels = 3 if a.config == "c3" else 2
     if a.batch == 0:
-        a.batch = 256 if a.config == "c3" else 1280
+        a.batch = 256 if a.config == "c3" else 2048
     return a
 
 
@@ -466,7 +466,7 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
     BASELINE configs[1] and the data-independent eager front-end -- each a short run of its own."""
     out = {}
     sweep = []
-    for b in (1, 8, 64, 256, 1280):
+    for b in (1, 8, 64, 256, 1024, 2048):
         if b > args.batch:
             continue
         el1 = run.timed(1, 1, n=b)

@@ -52,20 +52,25 @@
 #define TSTAMP(k) do { } while (0)
 #endif
 #ifndef FL_ICP_WPE
-#define FL_ICP_WPE 5               // waves per SIMD the 256-thread recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96)
+#define FL_ICP_WPE 4               // waves per SIMD the 256-thread recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96).  Measured
+                                  // on one box, ICP us per frame: 5 @ 1280 frames 11.65, 4 @ 1024 10.8, 4 @ 2048 10.4: the 96-VGPR build
+                                  // spills in the search loop
 #endif
 #ifndef FL_ICP_FAST_F32
 #define FL_ICP_FAST_F32 1          // FL_ICP_FAST keeps its per-thread partial sums (~60 terms) in float32, like the point-to-plane mode;
                                   // the cross-thread tree is fp64.  0: fp64 partials
 #endif
 #ifndef FL_ICP_FAST_WPE
-#define FL_ICP_FAST_WPE 5
+#define FL_ICP_FAST_WPE 4
 #endif
 #ifndef FL_ICP_PLANE_WPE
 #define FL_ICP_PLANE_WPE 4
 #endif
 // waves per SIMD kernel k_icp_pipeline<MODE, 256> is compiled for
 #define ICP_MODE_WPE(MODE) ((MODE) == FL_ICP_PARITY ? FL_ICP_WPE : ((MODE) == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE))
+#ifndef FL_ICP_NST
+#define FL_ICP_NST 4              // organised search: a staged window travels through 4 float4 registers per lane (256 points)
+#endif
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
@@ -673,12 +678,13 @@ __device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy,
   if (isfinite(r) && zlo > 1.0f) {                       // otherwise the whole crop (valid points have 0 < Z <= 900)
     const float ilo = __builtin_amdgcn_rcpf(zlo), ihi = __builtin_amdgcn_rcpf(zhi);
     const float xlo = qx - r, xhi = qx + r, ylo = qy - r, yhi = qy + r;
-    const float ful = floorf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - g.offu - 0.05f);
-    const float fuh = ceilf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.05f);
-    const float fvl = floorf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.05f);
-    const float fvh = ceilf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.05f);
+    // integer pixels u with t_lo - slop <= u <= t_hi + slop: ceil of the lower end, floor of the upper end
+    const float ful = ceilf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - g.offu - 0.05f);
+    const float fuh = floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.05f);
+    const float fvl = ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.05f);
+    const float fvh = floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.05f);
     const float cwm = (float)(g.cw - 1), chm = (float)(g.ch - 1);
-    if (fuh < 0.f || ful > cwm || fvh < 0.f || fvl > chm) { u_lo = 1; u_hi = 0; return; }
+    if (fuh < 0.f || ful > cwm || fvh < 0.f || fvl > chm || ful > fuh || fvl > fvh) { u_lo = 1; u_hi = 0; return; }
     u_lo = (int)fmaxf(ful, 0.f);
     u_hi = (int)fminf(fuh, cwm);
     v_lo = (int)fmaxf(fvl, 0.f);
@@ -933,61 +939,108 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
-        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step
+        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step.  Software pipeline: while step s is
+        // scanned from LDS, the window of step s + 1 has already been worked out and its points are on their way from
+        // memory into registers (R); they are written to the wave's LDS share once the scan of step s has been issued
+        // (LDS operations of a wave execute in order), so the memory round trip of the staging hides behind a scan.
         const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        constexpr int CAPW = (int)(sizeof(S.prod) / 16) / NW;       // points a wave can stage in its share of the chain tiles
+        constexpr int NST = FL_ICP_NST;                             // float4 registers per lane that hold a window on its way to LDS
+        constexpr int CAPL = (int)(sizeof(S.prod) / 16) / NW;       // points a wave's share of the chain tiles holds
+        constexpr int CAPW = CAPL < 64 * NST ? CAPL : 64 * NST;     // points a wave stages: larger unions are scanned from L2
         float4 *stage = (float4 *)&S.prod[0][0][0] + wv * CAPW;
         const float4 *refimg = sref;
-        const int last_s = n_model - 1;
+        const int last_s = n_model - 1, stride = NW * 64;
+        struct Win {
+          int u_lo, u_hi, v_lo, v_hi;        // this lane's window (crop pixels); a lane without one looks at (U0, V0)
+          int U0, V0, W, area, maxw, maxh;   // wave-uniform: union rectangle and the largest lane window
+          bool any, staged;                  // wave-uniform: some lane has a window; the union fits the LDS share
+        };
+        auto make_window = [&](const F3 &q, float b, bool queryable, Win &w) {
+          int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
+          if (queryable) org_window(og, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_thr)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_thr
+          const bool some = u_lo <= u_hi;
+          const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
+          w.any = U1 >= U0;
+          w.U0 = U0; w.V0 = 0; w.W = 1; w.area = 0; w.maxw = 0; w.maxh = 0; w.staged = false;
+          if (w.any) {
+            const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
+            w.maxw = wave_max_i(u_hi - u_lo + 1);
+            w.maxh = wave_max_i(v_hi - v_lo + 1);
+            if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one staged point: a real
+                                                                 // reference point beyond their radius, which the gate drops
+            w.V0 = V0;
+            w.W = U1 - U0 + 1;
+            w.area = w.W * (V1 - V0 + 1);
+            w.staged = w.area <= CAPW;
+          }
+          w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
+        };
+        auto issue_stage = [&](const Win &w, float4 (&R)[NST]) {
+          const float invW = 1.0f / (float)w.W;                // k / W below: exact for k < 2^20 (k + 0.5 keeps clear of the integers)
+#pragma unroll
+          for (int j = 0; j < NST; ++j) {
+            const int k = lane + 64 * j;
+            if (k < w.area) {
+              const int row = (int)(((float)k + 0.5f) * invW), col = k - row * w.W;
+              R[j] = ld_u32(refimg, (w.V0 + row) * og.cw + w.U0 + col);
+            }
+          }
+        };
+        auto write_stage = [&](const Win &w, const float4 (&R)[NST]) {
+#pragma unroll
+          for (int j = 0; j < NST; ++j) {
+            const int k = lane + 64 * j;
+            if (k < w.area) stage[k] = R[j];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        float4 R[NST];
+        Win wc, wn;
         int sb = wv * 64;
         int i_c = ld_u32(perm, min(sb + lane, last_s));
-        F3 q_c = ld3_u32(mod, i_c);
-        float b_c = ld_u32(bnd, i_c);
-        int i_n = ld_u32(perm, min(sb + NW * 64 + lane, last_s));
-        for (; sb < n_model; sb += NW * 64) {
-          const F3 q_n = ld3_u32(mod, i_n);
-          const float b_n = ld_u32(bnd, i_n);
-          const int i_nn = ld_u32(perm, min(sb + 2 * NW * 64 + lane, last_s));
+        int i_n = ld_u32(perm, min(sb + stride + lane, last_s));
+        int i_nn = ld_u32(perm, min(sb + 2 * stride + lane, last_s));
+        F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
+        float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
+        auto queryable_at = [&](int s, const F3 &q) { return s + lane < n_model && thr >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z); };
+        if (sb < n_model) {
+          make_window(q_c, b_c, queryable_at(sb, q_c), wc);
+          if (wc.any && wc.staged) issue_stage(wc, R);
+        }
+        for (; sb < n_model; sb += stride) {
+          if (wc.any && wc.staged) write_stage(wc, R);     // (waits for the loads issued one step ago)
+          const bool have_next = sb + stride < n_model;
+          if (have_next) {
+            make_window(q_n, b_n, queryable_at(sb + stride, q_n), wn);
+            if (wn.any && wn.staged) issue_stage(wn, R);
+          }
+          const F3 q_nn = ld3_u32(mod, i_nn);
+          const float b_nn = ld_u32(bnd, i_nn);
+          const int i_nnn = ld_u32(perm, min(sb + 3 * stride + lane, last_s));
           const int i = i_c;
           const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
           const bool active = sb + lane < n_model;
-          const bool queryable = active && thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
-          int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
-          if (queryable) org_window(og, qx, qy, qz, nn_radius(qx, qy, qz, fminf(b_c, r_thr)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_thr
-          const bool some = u_lo <= u_hi;
-          const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
+          const bool queryable = queryable_at(sb, q_c);
           int j = -1;
           float d = NAN;
-          if (U1 >= U0) {                                  // wave-uniform: at least one lane has a window
-            const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
-            const int maxw = wave_max_i(u_hi - u_lo + 1), maxh = wave_max_i(v_hi - v_lo + 1);
-            if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }   // lanes without a window look at one staged point: a real
-                                                             // reference point beyond their radius, which the gate drops
-            const int W = U1 - U0 + 1, H = V1 - V0 + 1, area = W * H;
+          if (wc.any) {                                    // wave-uniform: at least one lane has a window
 #ifdef FL_ICP_PHASES
             if (lane == 0) {
               atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
-              atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(maxw * maxh));
-              atomicAdd((unsigned long long *)&S.tacc[10], area <= CAPW ? 0ull : 1ull);
-              atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)area);
-              if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(maxw * maxh));
+              atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(wc.maxw * wc.maxh));
+              atomicAdd((unsigned long long *)&S.tacc[10], wc.staged ? 0ull : 1ull);
+              atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)wc.area);
+              if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(wc.maxw * wc.maxh));
             }
 #endif
             unsigned long long best;
-            if (area <= CAPW) {
-              const float invW = 1.0f / (float)W;            // k / W below: exact for k < 2^20 (k + 0.5 keeps clear of the integers)
-              for (int k = lane; k < area; k += 64) {
-                const int row = (int)(((float)k + 0.5f) * invW), col = k - row * W;
-                stage[k] = ld_u32(refimg, (V0 + row) * og.cw + U0 + col);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              best = org_scan([&](int idx) { return stage[idx]; }, W, U0, V0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, maxw, maxh);
-              __builtin_amdgcn_wave_barrier();               // the next step's staging overwrites what this scan read
-            } else {
-              best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, maxw, maxh);
-            }
+            if (wc.staged)
+              best = org_scan([&](int idx) { return stage[idx]; }, wc.W, wc.U0, wc.V0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw, wc.maxh);
+            else
+              best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw,
+                              wc.maxh);
             if (queryable) NN_UNPACK(best, &j, &d)
           }
           const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
@@ -999,7 +1052,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             ++kept;
             if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
           }
-          i_c = i_n; q_c = q_n; b_c = b_n; i_n = i_nn;
+          wc = wn;
+          i_c = i_n; q_c = q_n; b_c = b_n;
+          i_n = i_nn; q_n = q_nn; b_n = b_nn;
+          i_nn = i_nnn;
         }
       } else {
         const NnGrid G = nn_grid(S);

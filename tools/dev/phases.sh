@@ -3,5 +3,5 @@
 cd "$GRAFT_REPO_ROOT"
 export FL_ICP_PHASES=1
 for v in "$@"; do
-  B=${B:-1280} ARGS="--templates 360 --host-frames-steps 0 ${ARGS:-}" bash tools/dev/variants.sh "-DFL_ICP_PHASES $v"
+  B=${B:-1280} ARGS="--templates 360 --no-extras ${ARGS:-}" bash tools/dev/variants.sh "-DFL_ICP_PHASES $v"
 done

@@ -1,7 +1,9 @@
 """Turn the raw rocprofv3 output of tools/profile_round.sh (under gpurun_out/) into the committed summaries:
-profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc_b<batch>.json, profiles/<tag>_bench.json.
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json (stamped with the digest of the kernel sources it was
+collected on: bench.py quotes `traffic` from it only while that digest matches), profiles/<tag>_bench.json,
+profiles/<tag>_bench_c3.json.
 
-usage: python tools/profile_summarise.py r01_final [batch]
+usage: python tools/profile_summarise.py r02 [batch] [templates]
 """
 import collections
 import csv
@@ -14,6 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
+templates = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
 out = os.path.join(ROOT, "profiles")
 src = os.path.join(ROOT, "gpurun_out")
 
@@ -36,11 +39,16 @@ for f in newest.values():
         disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 kernels = {k: {c: acc[k][c] / max(1, len(disp[k][c])) for c in sorted(acc[k])} for k in sorted(acc) if k.startswith("k_") or "k_" in k}
 json.dump({
-    "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --batch %d --no-cpu-baseline" % batch,
+    "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --batch %d --templates %d "
+               "--no-cpu-baseline --no-extras" % (batch, templates),
+    "src_digest": open(os.path.join(src, "pmc_src_digest.txt")).read().strip(), "config": "c2",
     "note": "per-launch averages; FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 reports them (gfx950: FETCH_SIZE under-counts wide "
             "coalesced reads by up to 2x -- MI355X_MICROARCH.md); SQ_* cycle counters are quad-cycles summed over waves; "
             "separate passes per counter group (tools/profile_round.sh)",
-    "batch": batch, "templates": 360, "kernels": kernels}, open(os.path.join(out, f"{tag}_pmc_b{batch}.json"), "w"), indent=1)
+    "batch": batch, "templates": templates, "kernels": kernels}, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 line = [l for l in open(os.path.join(src, "bench_final.json")) if l.startswith("{")][-1]
 open(os.path.join(out, f"{tag}_bench.json"), "w").write(line)
+if os.path.exists(os.path.join(src, "bench_c3.json")):
+    line = [l for l in open(os.path.join(src, "bench_c3.json")) if l.startswith("{")][-1]
+    open(os.path.join(out, f"{tag}_bench_c3.json"), "w").write(line)
 print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag)))
