@@ -68,8 +68,17 @@
 #endif
 // waves per SIMD kernel k_icp_pipeline<MODE, 256> is compiled for
 #define ICP_MODE_WPE(MODE) ((MODE) == FL_ICP_PARITY ? FL_ICP_WPE : ((MODE) == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE))
+#ifndef FL_ICP_PIPE
+#define FL_ICP_PIPE 0             // organised search, 1: the next step's window is fetched into registers while this step is scanned and
+                                  // written to LDS afterwards.  Measured slower (22.05 vs 21.59 ms per 2048 frames): the extra live
+                                  // registers spill inside the loop, and every scratch reload waits for ALL loads in flight
+#endif
+#ifndef FL_ICP_NBQ
+#define FL_ICP_NBQ 4              // organised search: candidate positions fetched per batch (4 VGPRs each)
+#endif
 #ifndef FL_ICP_NST
-#define FL_ICP_NST 4              // organised search: a staged window travels through 4 float4 registers per lane (256 points)
+#define FL_ICP_NST 6              // organised search: a staged window travels through up to 6 float4 registers per lane (the whole LDS
+                                  // share of the wave: 367 points; 4 -> 20.95 vs 21.59 ms per 2048 frames, more windows scanned from L2)
 #endif
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
@@ -654,6 +663,7 @@ struct OrgGeom {
   int cw, ch;            // crop size: refimg[v * cw + u] holds the point of crop pixel (u, v)
   float offu, offv;      // scene pixel of crop pixel (0, 0) minus the principal point
   float fx, fy;
+  float cwm, chm;        // (float)(cw - 1), (float)(ch - 1)
 };
 // whole-wave minimum / maximum of an int by DPP (row_shr 1, 2, 4, 8, row_bcast 15 / 31), returned as a wave-uniform value
 #define FL_DPP_RED(OP, IDENT)                                                                                 \
@@ -683,44 +693,37 @@ __device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy,
     const float fuh = floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.05f);
     const float fvl = ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.05f);
     const float fvh = floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.05f);
-    const float cwm = (float)(g.cw - 1), chm = (float)(g.ch - 1);
-    if (fuh < 0.f || ful > cwm || fvh < 0.f || fvl > chm || ful > fuh || fvl > fvh) { u_lo = 1; u_hi = 0; return; }
-    u_lo = (int)fmaxf(ful, 0.f);
-    u_hi = (int)fminf(fuh, cwm);
-    v_lo = (int)fmaxf(fvl, 0.f);
-    v_hi = (int)fminf(fvh, chm);
+    // to integers first (clamped far outside any crop), then compared with the crop size as integers: cw and ch are
+    // wave-uniform and stay scalar operands
+    const int iul = (int)fminf(fmaxf(ful, -1.0e6f), 1.0e6f), iuh = (int)fminf(fmaxf(fuh, -1.0e6f), 1.0e6f);
+    const int ivl = (int)fminf(fmaxf(fvl, -1.0e6f), 1.0e6f), ivh = (int)fminf(fmaxf(fvh, -1.0e6f), 1.0e6f);
+    if (iuh < 0 || iul > g.cw - 1 || ivh < 0 || ivl > g.ch - 1 || iul > iuh || ivl > ivh) { u_lo = 1; u_hi = 0; return; }
+    u_lo = max(iul, 0);
+    u_hi = min(iuh, g.cw - 1);
+    v_lo = max(ivl, 0);
+    v_hi = min(ivh, g.ch - 1);
   }
 }
 
-// every lane's window enumerated in lockstep, maxh rows of maxw positions, 4 positions per batch and the next batch in flight
-// while one is evaluated (lanes with a smaller window re-read their own last column / row: duplicates do not change a
-// minimum); fetch((v - ov) * RS + (u - ou)) returns the point of crop pixel (u, v)
+// every lane's window enumerated in lockstep, maxh rows of maxw positions, FL_ICP_NBQ positions per batch (lanes with a
+// smaller window re-read their own last column / row: duplicates do not change a minimum);
+// fetch((v - ov) * RS + (u - ou)) returns the point of crop pixel (u, v)
 template <typename F>
 __device__ __forceinline__ unsigned long long org_scan(F fetch, int RS, int ou, int ov, float qx, float qy, float qz, int u_lo, int u_hi,
                                                        int v_lo, int v_hi, int maxw, int maxh)
 {
+  constexpr int NBQ = FL_ICP_NBQ;
   unsigned long long best = NN_KEY_NONE;
   const int wl = u_hi - u_lo, hl = v_hi - v_lo;
   const int b0 = (v_lo - ov) * RS + (u_lo - ou);
-  const int nbw = (maxw + 3) >> 2, nb = nbw * maxh;       // batches per row, batches in all (wave-uniform)
-  float4 cur[4], nxt[4];
-  int du = 0, dv = 0;                                      // of the batch being fetched (wave-uniform)
-  auto fetch_batch = [&](float4 (&p)[4]) {
+  for (int dv = 0; dv < maxh; ++dv) {
     const int rb = b0 + min(dv, hl) * RS;
+    for (int du = 0; du < maxw; du += NBQ) {               // one batch at a time: the other waves of the SIMD cover the LDS latency
+      float4 cur[NBQ];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) p[e] = fetch(rb + min(du + e, wl));
-    du += 4;
-    if (du >= maxw) { du = 0; ++dv; }
-  };
-  if (nb > 0) fetch_batch(cur);
-  for (int b = 0; b < nb; b += 2) {                        // ping-pong: no register copies between batches
-    if (b + 1 < nb) fetch_batch(nxt);
+      for (int e = 0; e < NBQ; ++e) cur[e] = fetch(rb + min(du + e, wl));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
-    if (b + 1 < nb) {
-      if (b + 2 < nb) fetch_batch(cur);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) NN_CONSIDER(nxt[e])
+      for (int e = 0; e < NBQ; ++e) NN_CONSIDER(cur[e])
     }
   }
   return best;
@@ -894,8 +897,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     // with 3*dist_mean (Q9), which parity/fast keep
     if (threadIdx.x == 0) { ++S.iter; S.thr = plane ? (3 * S.dist_mean) * (3 * S.dist_mean) : 3 * S.dist_mean; }
     __syncthreads();
-    const int iter = S.iter;
-    const float thr = S.thr;
+    const int iter = __builtin_amdgcn_readfirstlane(S.iter);
+    const float thr = uniform_f(S.thr);
     const int rows = iter == 1 ? n_ref : n_model;
     constexpr bool parity = MODE == FL_ICP_PARITY;
     constexpr int mode = MODE;
@@ -939,10 +942,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
-        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step.  Software pipeline: while step s is
-        // scanned from LDS, the window of step s + 1 has already been worked out and its points are on their way from
-        // memory into registers (R); they are written to the wave's LDS share once the scan of step s has been issued
-        // (LDS operations of a wave execute in order), so the memory round trip of the staging hides behind a scan.
+        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  (FL_ICP_PIPE=1
+        // software-pipelines the staging one step ahead through registers; measured slower, see the macro.)
         const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         constexpr int NST = FL_ICP_NST;                             // float4 registers per lane that hold a window on its way to LDS
         constexpr int CAPL = (int)(sizeof(S.prod) / 16) / NW;       // points a wave's share of the chain tiles holds
@@ -1005,17 +1006,24 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
         float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
         auto queryable_at = [&](int s, const F3 &q) { return s + lane < n_model && thr >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z); };
+#if FL_ICP_PIPE
         if (sb < n_model) {
           make_window(q_c, b_c, queryable_at(sb, q_c), wc);
           if (wc.any && wc.staged) issue_stage(wc, R);
         }
+#endif
         for (; sb < n_model; sb += stride) {
+#if FL_ICP_PIPE
           if (wc.any && wc.staged) write_stage(wc, R);     // (waits for the loads issued one step ago)
           const bool have_next = sb + stride < n_model;
           if (have_next) {
             make_window(q_n, b_n, queryable_at(sb + stride, q_n), wn);
             if (wn.any && wn.staged) issue_stage(wn, R);
           }
+#else
+          make_window(q_c, b_c, queryable_at(sb, q_c), wc);
+          if (wc.any && wc.staged) { issue_stage(wc, R); write_stage(wc, R); }
+#endif
           const F3 q_nn = ld3_u32(mod, i_nn);
           const float b_nn = ld_u32(bnd, i_nn);
           const int i_nnn = ld_u32(perm, min(sb + 3 * stride + lane, last_s));
@@ -1052,7 +1060,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             ++kept;
             if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
           }
+#if FL_ICP_PIPE
           wc = wn;
+#endif
           i_c = i_n; q_c = q_n; b_c = b_n;
           i_n = i_nn; q_n = q_nn; b_n = b_nn;
           i_nn = i_nnn;
@@ -1485,7 +1495,7 @@ __global__ __launch_bounds__(BS) void k_icp_clouds(IcpArgs a)
   SH &S = *(SH *)icp_smem;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
-  const OrgGeom none = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  const OrgGeom none = {0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   icp_run<MODE, false>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp, none);
 }
 
@@ -1571,7 +1581,10 @@ void k_icp_pipeline(IcpArgs a)
   float4 *refimg = (float4 *)(wsb + L.sref);
   const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod,
                              MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr, refimg);
-  const OrgGeom og = {S.rect_r[2], S.rect_r[3], (float)S.rect_r[0] - a.cx, (float)S.rect_r[1] - a.cy, a.fx, a.fy};
+  // wave-uniform values read from LDS are VGPRs unless told otherwise: the search loop keeps them in SGPRs
+  const OrgGeom og = {__builtin_amdgcn_readfirstlane(S.rect_r[2]), __builtin_amdgcn_readfirstlane(S.rect_r[3]),
+                      uniform_f((float)S.rect_r[0] - a.cx), uniform_f((float)S.rect_r[1] - a.cy), a.fx, a.fy,
+                      uniform_f((float)(S.rect_r[2] - 1)), uniform_f((float)(S.rect_r[3] - 1))};
   build_tile_order(S, refimg, og.cw, og.ch, np, (int *)(wsb + L.perm));
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
