@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfealess_hip.so")
+# FEALESS_HIP_LIB: development knob -- another build of the same library (A/B timing of two builds on one GPU box)
+LIB_PATH = os.environ.get("FEALESS_HIP_LIB") or os.path.join(_HERE, "csrc", "libfealess_hip.so")
 
 FL_OK = 0
 FL_ERR_INVALID, FL_ERR_HIP, FL_ERR_ASSERT, FL_ERR_OVERFLOW, FL_ERR_NO_DEVICE, FL_ERR_STATE, FL_ERR_NO_TEMPLATE = -1, -2, -3, -4, -5, -6, -7

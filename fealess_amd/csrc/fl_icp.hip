@@ -998,7 +998,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         float4 R[NST];
-        Win wc, wn;
+        Win wc;
+#if FL_ICP_PIPE
+        Win wn;
+#endif
         int sb = wv * 64;
         int i_c = ld_u32(perm, min(sb + lane, last_s));
         int i_n = ld_u32(perm, min(sb + stride + lane, last_s));
