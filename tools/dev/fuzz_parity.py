@@ -12,7 +12,7 @@ os.environ.setdefault("FL_DEV_POISON", "1")   # lazy fine levels: poison what th
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 ctx = api.Context(0)
 t0 = time.time()
-stats = dict(icp=0, frontend=0, recognition=0, linemod=0, extract=0, fail=0)
+stats = dict(icp=0, frontend=0, recognition=0, linemod=0, extract=0, detection=0, fail=0)
 def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
 seed = int(os.environ.get("FUZZ_SEED", "1000"))
 last_print = t0
@@ -22,7 +22,7 @@ while time.time() - t0 < budget:
         last_print = time.time()
         print("progress:", stats, flush=True)
     rng = np.random.default_rng(seed)
-    kind = seed % 5 if len(sys.argv) < 3 else int(sys.argv[2])
+    kind = seed % 6 if len(sys.argv) < 3 else int(sys.argv[2])
     try:
         if kind == 0:      # ICP on random paired clouds of random size / misalignment / noise / invalid points
             n = int(rng.integers(3, 9000))
@@ -70,14 +70,36 @@ while time.time() - t0 < budget:
             ax, sh = int(rng.integers(0, 2)), int(rng.integers(-300, 300))
             fb = [sc["bgr"], np.roll(sc["bgr"], sh, axis=ax)]
             fd = [sc["depth"], np.roll(sc["depth"], sh, axis=ax)]
-            rs = det.recognize_batch(fb, fd, sc["K"], thr, it, 0.3, 0.01)
+            # the caller's intrinsics need not be the camera's: the organised search projects with whatever it is given
+            K = tuple(float(v) for v in (np.array(sc["K"]) * rng.uniform(0.97, 1.03, 4))) if rng.random() < 0.5 else sc["K"]
+            rs = det.recognize_batch(fb, fd, K, thr, it, 0.3, 0.01)
             ok = True
             for b_, d_, r in zip(fb, fd, rs):
-                e = O.recognition(b_, d_, sc["K"], T, sc["bank"], thr, it, 0.3, 0.01)
+                e = O.recognition(b_, d_, K, T, sc["bank"], thr, it, 0.3, 0.01)
                 ok = ok and r["found"] == e["found"] and r["n_matches"] == e["n_matches"] and \
                     (not e["found"] or np.array_equal(bits(r["pose"]), bits(e["pose"])))
             det.close()
             stats["recognition"] += 1
+        elif kind == 5:    # detection(): random crop rectangles, poses, intrinsics and iteration counts (organised search, 1024-thread kernel)
+            R, t = synth.object_pose(tx=float(rng.uniform(-60, 60)), ty=float(rng.uniform(-40, 40)), tz=float(rng.uniform(560, 800)),
+                                     yaw=float(rng.uniform(-0.5, 0.5)), tilt=float(rng.uniform(0.2, 0.5)), roll=float(rng.uniform(-0.2, 0.2)))
+            scene, _, ms = synth.render(640, 480, R, t, seed=seed, noise=True, background=bool(rng.integers(0, 2)))
+            dR = synth.rot_z(rng.uniform(-.06, .06)) @ synth.rot_x(rng.uniform(-.05, .05)) @ synth.rot_y(rng.uniform(-.05, .05))
+            tm = t + rng.uniform(-25, 25, 3) * np.array([1, 1, 0.3])
+            model, _, mm = synth.render(640, 480, dR @ R, tm, seed=seed + 7, noise=False, background=False)
+            ys, xs = np.nonzero(ms); ym, xm = np.nonzero(mm)
+            cw = int(min(max(xs.max() - xs.min(), xm.max() - xm.min()) + rng.integers(0, 12), 600))
+            ch = int(min(max(ys.max() - ys.min(), ym.max() - ym.min()) + rng.integers(0, 12), 440))
+            rr = (int(np.clip(xs.min() - rng.integers(0, 6), 0, 640 - cw)), int(np.clip(ys.min() - rng.integers(0, 6), 0, 480 - ch)), cw, ch)
+            rm = (int(np.clip(xm.min() - rng.integers(0, 6), 0, 640 - cw)), int(np.clip(ym.min() - rng.integers(0, 6), 0, 480 - ch)), cw, ch)
+            K = tuple(float(v) for v in (np.array([608.0, 608.0, 320.0, 240.0]) * rng.uniform(0.95, 1.05, 4)))
+            a = (model, scene, K, rm, rr, int(rng.integers(1, 14)), float(rng.choice([0.0, 0.3])), float(rng.choice([-3e38, 0.01])),
+                 (dR @ R).astype(np.float32), tm.astype(np.float32))
+            g = ctx.detection(*a, L.FL_ICP_PARITY)
+            e = O.detection(*a)
+            ok = g["n_points"] == e["n_points"] and g["icp"]["iters"] == e["icp"]["iters"] and \
+                np.array_equal(bits(g["R_final"]), bits(e["R_final"])) and np.array_equal(bits(g["T_final"]), bits(e["T_final"]))
+            stats["detection"] += 1
         elif kind == 4:    # template extraction (addTemplate) on a random view, with / without mask, 1-3 levels
             R, t = synth.object_pose(tx=float(rng.uniform(-60, 60)), ty=float(rng.uniform(-40, 40)), tz=float(rng.uniform(560, 760)),
                                      yaw=float(rng.uniform(-0.5, 0.5)), tilt=float(rng.uniform(0.2, 0.5)), roll=float(rng.uniform(-0.2, 0.2)))
