@@ -52,7 +52,7 @@ def parse():
                     help="frames per step per GPU (default 2048 for c2 = two rounds of 4 ICP workgroups on each of the 256 CUs; 256 for c3)")
     ap.add_argument("--icp-iters", type=int, default=20)
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
-    ap.add_argument("--scenes", type=int, default=8)
+    ap.add_argument("--scenes", type=int, default=16)
     ap.add_argument("--shard", choices=["frames", "templates"], default="frames")
     ap.add_argument("--topk", type=int, default=64, help="records per rank in the template-sharded all-gather")
     ap.add_argument("--verify-sharded", action="store_true",
@@ -126,13 +126,13 @@ def build_bank(ctx, args, n_templates, w, h, K):
 
 
 def build_frames(scenes, B, rank, w, h, same_on_all_ranks=False):
-    """Per-rank frames: scene s rolled sideways by a rank/frame dependent even amount."""
+    """Per-rank frames: scene s rolled sideways by a rank/frame dependent even amount (-24 .. +22 px)."""
     bgrs = np.empty((B, h, w, 3), np.uint8)
     depths = np.empty((B, h, w), np.uint16)
     r = 0 if same_on_all_ranks else rank
     for i in range(B):
         b, d = scenes[i % len(scenes)]
-        sh = 2 * (((i // len(scenes)) + 3 * r) % 12) - 12
+        sh = 2 * (((i // len(scenes)) + 5 * r) % 24) - 24
         bgrs[i] = np.roll(b, sh, axis=1)
         depths[i] = np.roll(d, sh, axis=1)
     return bgrs, depths
@@ -417,7 +417,7 @@ def line_c2(args, run, res, times, value, el, world, bank, T, bgrs, depths, sync
                                f"dist_diff_thr=-3e38), ICP mode {args.icp_mode}",
                    "frames_per_step_per_gpu": B, "templates": bank.n_pyramids, "levels": args.levels,
                    "parallelism": f"frame-sharded x{world}",
-                   "distinct_frames": f"{min(B, 12 * args.scenes)} ({args.scenes} scenes x 12 shifts)",
+                   "distinct_frames": f"{min(B, 24 * args.scenes)} ({args.scenes} scenes x 24 sideways shifts of 2 px)",
                    "fine_levels": "eager (whole images, before the scan)" if args.eager_frontend else
                                   "lazy (tiles the scan's candidates touch: data-dependent, see eager_frontend for whole images)"},
         "ms_per_icp_iter": round(times["icp_ms"] / max(1, args.icp_iters), 5),

@@ -13,6 +13,13 @@ from . import _lib as L
 from .bank import MATCH_DTYPE, TemplateBank
 
 
+# numpy view of fl_recognition_result (include/fealess_hip.h), for bulk access to result arrays
+_ICP_DT = np.dtype([("R", "<f4", 9), ("T", "<f4", 3), ("dist_mean", "<f4"), ("px_ratio", "<f4"), ("iters", "<i4"), ("n_corr_last", "<i4")])
+_DET_DT = np.dtype([("R_final", "<f4", 9), ("T_final", "<f4", 3), ("icp", _ICP_DT), ("n_points", "<i4"), ("status", "<i4")])
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("found", "<i4"), ("n_matches", "<i4"), ("best", MATCH_DTYPE), ("pose", "<f4", 16), ("det", _DET_DT)])
+assert RESULT_DTYPE.itemsize == C.sizeof(L.RecognitionResult)
+
+
 class FealessError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"fealess_hip error {code}: {msg}")

@@ -83,7 +83,31 @@ def owner_of(template_id, n_templates, world):
     raise ValueError(f"template {template_id} outside 0..{n_templates}")
 
 
-def template_sharded_recognize(n_frames, k, n_templates, world, rank, local_topk, allgather, refine, allreduce_sum):
+def owners_of(template_ids, n_templates, world):
+    """Vectorised owner_of: int array of ranks (-1 where the id is negative)."""
+    firsts = np.array([shard_range(n_templates, world, r)[0] for r in range(world)], np.int64)
+    t = np.asarray(template_ids, np.int64)
+    return np.where(t >= 0, np.searchsorted(firsts, t, side="right") - 1, -1).astype(np.int32)
+
+
+def best_of_ranks(gathered):
+    """matches[0] of one global std::sort over all ranks' lists, per frame, without merging the lists: every rank's list is
+    already sorted, so the global first element is the first of the ranks' first elements in the same order
+    (similarity descending, then template id, class, y, x ascending -- fl_merge_topk's comparator).
+    gathered: MATCH_DTYPE [world, n_frames, k]; returns MATCH_DTYPE [n_frames] (template_id = -1 where no rank matched)."""
+    heads = np.ascontiguousarray(gathered[:, :, 0])                 # [world, n_frames]
+    world, n_frames = heads.shape
+    valid = heads["template_id"] >= 0
+    # np.lexsort: last key is the primary one
+    sim = np.where(valid, heads["similarity"], -np.inf)
+    order = np.lexsort((heads["x"].T, heads["y"].T, heads["class_idx"].T, np.where(valid, heads["template_id"], np.iinfo(np.int32).max).T,
+                        -sim.T), axis=1)                            # [n_frames, world]: ranks in match order
+    win = order[:, 0]
+    best = heads[win, np.arange(n_frames)].copy()
+    return best
+
+
+def template_sharded_recognize(n_frames, k, n_templates, world, rank, local_topk, allgather, refine, allreduce_sum, full_lists=False):
     """Recognition() of n_frames frames against a bank sharded over `world` ranks -- the host logic, with the device work
     behind four callables so that the CPU tests (gloo + oracle) and the GPU path (RCCL + HIP detector) run the same code:
 
@@ -94,22 +118,26 @@ def template_sharded_recognize(n_frames, k, n_templates, world, rank, local_topk
                                  this rank owns (`matches` carry class-local ids of this rank's shard)
       allreduce_sum(array)    -> the elementwise sum over ranks of a float32 numpy array (every rank gets it)
 
-    Returns (merged first matches MATCH_DTYPE [n_frames] with global ids and template_id = -1 where nothing matched,
-             n_matches per frame (capped at k), poses float32 [n_frames, 17])."""
-    from .api import merge_topk_batch
+    Recognition() only ever uses matches[0] (obj_reco_lmicp.cpp:111), which is the best of the ranks' best records
+    (best_of_ranks); full_lists=True also merges the whole lists as one Detector::match would order them
+    (fl_merge_topk_batch) and returns their lengths (capped at k), otherwise n_matches is None.
+
+    Returns (first match per frame, MATCH_DTYPE [n_frames], global ids, template_id = -1 where nothing matched;
+             n_matches per frame or None; poses float32 [n_frames, 17])."""
     first, _count = shard_range(n_templates, world, rank)
-    gathered = allgather(local_topk())
-    merged, n_out = merge_topk_batch(np.ascontiguousarray(gathered).reshape(-1), world, n_frames, k, k)
-    best = np.zeros(n_frames, MATCH_DTYPE)
-    best["template_id"] = -1
-    has = n_out > 0
-    best[has] = merged[has, 0]
+    gathered = np.ascontiguousarray(allgather(local_topk())).reshape(world, n_frames, k)
+    best = best_of_ranks(gathered)
+    n_out = None
+    if full_lists:
+        from .api import merge_topk_batch
+        merged, n_out = merge_topk_batch(gathered.reshape(-1), world, n_frames, k, k)
+        has = n_out > 0
+        assert np.array_equal(merged[has, 0], best[has]) and (best["template_id"][~has] < 0).all()
     # one global std::sort + unique, then matches[0] (linemod.cpp:1437-1439, obj_reco_lmicp.cpp:111): its owner refines it
-    mine = [f for f in range(n_frames) if has[f] and owner_of(int(best["template_id"][f]), n_templates, world) == rank]
+    mine = np.nonzero(owners_of(best["template_id"], n_templates, world) == rank)[0]
     poses = np.zeros((n_frames, 17), np.float32)
-    if mine:
+    if len(mine):
         jobs = best[mine].copy()
         jobs["template_id"] -= first
-        out = refine(mine, jobs)
-        poses[mine] = out
+        poses[mine] = refine(mine.tolist(), jobs)
     return best, n_out, allreduce_sum(poses)

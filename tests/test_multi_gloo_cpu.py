@@ -112,7 +112,7 @@ def _worker_recognize(rank, world, port, out_dir):
         dist.all_reduce(t)
         return t.numpy()
 
-    best, n_out, poses = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk, allgather, refine, allreduce_sum)
+    best, n_out, poses = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk, allgather, refine, allreduce_sum, full_lists=True)
     ok = True
     owners = []
     for f, (b, d) in enumerate(frames):
@@ -147,3 +147,37 @@ def test_shard_range_properties():
             for (a, ca), (b, _) in zip(spans, spans[1:]):
                 assert a + ca == b
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_best_of_ranks_equals_first_of_the_merged_list():
+    """The fast path of template_sharded_recognize: matches[0] of the global sort = the best of the ranks' first records,
+    against fl_merge_topk_batch on random sorted per-rank lists (ties in similarity and template id included)."""
+    sys.path.insert(0, ROOT)
+    from fealess_amd import distributed as D
+    from fealess_amd.api import merge_topk_batch
+    from fealess_amd.bank import MATCH_DTYPE
+    rng = np.random.default_rng(5)
+    world, n_frames, k, n_templates = 4, 50, 8, 103
+    g = np.zeros((world, n_frames, k), MATCH_DTYPE)
+    g["template_id"] = -1
+    g["class_idx"] = -1
+    for r in range(world):
+        first, count = D.shard_range(n_templates, world, r)
+        for f in range(n_frames):
+            n = int(rng.integers(0, k + 1))
+            rec = np.zeros(n, MATCH_DTYPE)
+            rec["similarity"] = rng.choice(np.array([80.0, 85.5, 90.25, 97.0], np.float32), n)   # few values: many ties
+            rec["template_id"] = first + rng.integers(0, count, n)
+            rec["x"], rec["y"] = rng.integers(0, 640, n), rng.integers(0, 480, n)
+            rec = rec[np.lexsort((rec["x"], rec["y"], rec["class_idx"], rec["template_id"], -rec["similarity"]))]
+            g[r, f, :n] = rec
+    best = D.best_of_ranks(g)
+    merged, n_out = merge_topk_batch(g.reshape(-1), world, n_frames, k, k)
+    for f in range(n_frames):
+        if n_out[f] == 0:
+            assert best["template_id"][f] < 0
+        else:
+            assert best[f] == merged[f, 0], f
+    own = D.owners_of(best["template_id"], n_templates, world)
+    for f in range(n_frames):
+        assert own[f] == (D.owner_of(int(best["template_id"][f]), n_templates, world) if best["template_id"][f] >= 0 else -1)
