@@ -474,3 +474,47 @@ def test_context_outlives_its_detectors_in_either_destroy_order():
     det.finalize(640, 480)
     c.close()                # deferred: the detector is still alive
     det.close()              # releases the context
+
+
+def test_hard_candidate_cap_fails_only_the_cluttered_frame(ctx, oracle):
+    """max_candidates < 0 asks for a hard cap: a frame that exceeds it reports FL_ERR_OVERFLOW in its own status and the other
+    frame of the batch keeps its (oracle-equal) result -- one bad frame must not take a batch down."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=5, n_views=4, n_random=20)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480, max_batch=2, max_candidates=-256)
+    blank_b, blank_d = np.zeros_like(sc["bgr"]), np.zeros_like(sc["depth"])          # no gradient, no depth return: no candidates at all
+    got = det.recognize_batch([sc["bgr"], blank_b], [sc["depth"], blank_d], sc["K"], -100.0, 6, 0.0, -3.0e38)
+    assert got[0]["status"] == L.FL_ERR_OVERFLOW and got[0]["found"] == 0
+    e = oracle.recognition(blank_b, blank_d, sc["K"], [5, 8], sc["bank"], -100.0, 6, 0.0, -3.0e38)
+    assert got[1]["status"] == 0 and got[1]["found"] == e["found"] and got[1]["n_matches"] == e["n_matches"]
+    det.close()
+
+
+def test_refine_matches_argument_checks_and_result(ctx, oracle):
+    """fl_refine_matches = the second half of Recognition() for a match the caller chose: refining the detector's own best
+    match must give fl_recognize_batch's pose; wrong frames / templates / call order are refused."""
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=9, n_views=4, n_random=6)
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(sc["bank"])
+    det.finalize(640, 480, max_batch=2)
+    params = L.RecognitionParams(75.0, 7, 0.0, -3.0e38, L.FL_ICP_PARITY)
+    one = np.zeros(1, api.MATCH_DTYPE)
+    with pytest.raises(api.FealessError) as ex:
+        det.refine_matches([0], one, sc["K"], params)                 # nothing matched yet
+    assert ex.value.code == L.FL_ERR_STATE
+    ref = det.recognize_batch([sc["bgr"]], [sc["depth"]], sc["K"], 75.0, 7, 0.0, -3.0e38)[0]
+    lists = det.match_batch([sc["bgr"], sc["bgr"]], [sc["depth"], sc["depth"]], 75.0)
+    best = lists[1][0][:1]
+    res = det.refine_matches([1], best, sc["K"], params)
+    assert res[0].found == 1 and np.array_equal(_bits(np.array(list(res[0].pose), np.float32)), _bits(ref["pose"].reshape(-1)))
+    for frames, m in (([2], best), ([-1], best)):
+        with pytest.raises(api.FealessError) as ex:
+            det.refine_matches(frames, m, sc["K"], params)
+        assert ex.value.code == L.FL_ERR_INVALID
+    bad = best.copy()
+    bad["template_id"] = sc["bank"].n_pyramids
+    with pytest.raises(api.FealessError) as ex:
+        det.refine_matches([0], bad, sc["K"], params)
+    assert ex.value.code == L.FL_ERR_INVALID
+    det.close()
