@@ -679,7 +679,7 @@ __device__ __forceinline__ int wave_max_i(int v) { FL_DPP_RED(max, (int)0x800000
 
 // The crop pixels whose points can lie within distance r of q: a point (X, Y, Z) of pixel (su, sv) satisfies
 // su - cx = X fx / Z up to float rounding (it was generated as X = ((su - cx) / fx) Z), and |X - qx|, |Z - qz| <= r.
-// The 0.05-pixel slop is two orders of magnitude above that rounding.  An empty window has u_lo > u_hi.
+// The 0.01-pixel slop is an order of magnitude above that rounding (5e-7 relative on |su - cx| <= 2000 pixels).  An empty window has u_lo > u_hi.
 __device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy, float qz, float r, int &u_lo, int &u_hi, int &v_lo,
                                            int &v_hi)
 {
@@ -689,10 +689,10 @@ __device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy,
     const float ilo = __builtin_amdgcn_rcpf(zlo), ihi = __builtin_amdgcn_rcpf(zhi);
     const float xlo = qx - r, xhi = qx + r, ylo = qy - r, yhi = qy + r;
     // integer pixels u with t_lo - slop <= u <= t_hi + slop: ceil of the lower end, floor of the upper end
-    const float ful = ceilf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - g.offu - 0.05f);
-    const float fuh = floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.05f);
-    const float fvl = ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.05f);
-    const float fvh = floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.05f);
+    const float ful = ceilf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - g.offu - 0.01f);
+    const float fuh = floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.01f);
+    const float fvl = ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.01f);
+    const float fvh = floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.01f);
     // to integers first (clamped far outside any crop), then compared with the crop size as integers: cw and ch are
     // wave-uniform and stay scalar operands
     const int iul = (int)fminf(fmaxf(ful, -1.0e6f), 1.0e6f), iuh = (int)fminf(fmaxf(fuh, -1.0e6f), 1.0e6f);
@@ -977,14 +977,20 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
         };
         auto issue_stage = [&](const Win &w, float4 (&R)[NST]) {
-          const float invW = 1.0f / (float)w.W;                // k / W below: exact for k < 2^20 (k + 0.5 keeps clear of the integers)
+          // slot k = lane + 64 t holds point (k / W, k % W) of the union rectangle: one division (by reciprocal: exact for
+          // k < 2^20, k + 0.5 keeps clear of the integers) for t = 0, then (row, col) advance by 64 slots incrementally;
+          // all products fit 24 bits
+          const float invW = 1.0f / (float)w.W;
+          int row = (int)(((float)lane + 0.5f) * invW), col = lane - row * w.W;
+          const int drow = (int)(64.5f * invW), dcol = 64 - drow * w.W;      // 64 = drow * W + dcol (wave-uniform)
+          int idx = (int)__umul24((unsigned)(w.V0 + row), (unsigned)og.cw) + w.U0 + col;
+          const int didx = (int)__umul24((unsigned)drow, (unsigned)og.cw) + dcol;
 #pragma unroll
           for (int j = 0; j < NST; ++j) {
-            const int k = lane + 64 * j;
-            if (k < w.area) {
-              const int row = (int)(((float)k + 0.5f) * invW), col = k - row * w.W;
-              R[j] = ld_u32(refimg, (w.V0 + row) * og.cw + w.U0 + col);
-            }
+            if (lane + 64 * j < w.area) R[j] = ld_u32(refimg, idx);
+            col += dcol;
+            idx += didx;
+            if (col >= w.W) { col -= w.W; idx += og.cw - w.W; }
           }
         };
         auto write_stage = [&](const Win &w, const float4 (&R)[NST]) {
