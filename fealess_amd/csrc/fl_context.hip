@@ -147,6 +147,7 @@ extern "C" int fl_detector_create(fl_context *ctx, int modalities, int levels, c
 static void free_device_tables(fl_detector *det)
 {
   (void)hipFree(det->d_scan_hdr);
+  (void)hipFree(det->d_scan_items);
   (void)hipFree(det->d_scan_off);
   (void)hipFree(det->d_fine_hdr);
   (void)hipFree(det->d_fine_feat);
@@ -159,6 +160,8 @@ static void free_device_tables(fl_detector *det)
   (void)hipFree(det->d_results);
   if (det->h_results) (void)hipHostFree(det->h_results);
   det->d_scan_hdr = nullptr;
+  det->d_scan_items = nullptr;
+  det->n_scan_items = 0;
   det->d_scan_off = nullptr;
   det->d_fine_hdr = nullptr;
   det->d_fine_feat = nullptr;
@@ -513,6 +516,19 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
 
   int rc;
   if ((rc = upload(ctx, scan_hdr, &det->d_scan_hdr))) return rc;
+  {
+    // k_scan's work list: one wave per (pyramid, chunk of 1024 coarse positions) -- only the chunks some modality's
+    // template_positions reach (a 160-pixel template at VGA level 1 has P = 831 of 1200 cells: its second chunk is empty)
+    std::vector<int2> items;
+    const int nchunks = (det->geom[L - 1].WH + 1023) / 1024;
+    for (int g = 0; g < g_idx; ++g) {
+      int pmax = 0;
+      for (int m = 0; m < M; ++m) pmax = std::max(pmax, (int)scan_hdr[(size_t)g * M + m].P);
+      for (int c = 0; c < nchunks && (c == 0 || c * 1024 < pmax); ++c) items.push_back(make_int2(g, c));   // chunk 0 always: the debug tap zero-fills through it
+    }
+    det->n_scan_items = (int)items.size();
+    if ((rc = upload(ctx, items, &det->d_scan_items))) return rc;
+  }
   if ((rc = upload(ctx, scan_off, &det->d_scan_off))) return rc;
   if ((rc = upload(ctx, fine_hdr, &det->d_fine_hdr))) return rc;
   if ((rc = upload(ctx, fine_feat, &det->d_fine_feat))) return rc;

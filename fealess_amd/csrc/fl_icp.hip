@@ -68,11 +68,6 @@
 #endif
 // waves per SIMD kernel k_icp_pipeline<MODE, 256> is compiled for
 #define ICP_MODE_WPE(MODE) ((MODE) == FL_ICP_PARITY ? FL_ICP_WPE : ((MODE) == FL_ICP_POINT_TO_PLANE ? FL_ICP_PLANE_WPE : FL_ICP_FAST_WPE))
-#ifndef FL_ICP_PIPE
-#define FL_ICP_PIPE 0             // organised search, 1: the next step's window is fetched into registers while this step is scanned and
-                                  // written to LDS afterwards.  Measured slower (22.05 vs 21.59 ms per 2048 frames): the extra live
-                                  // registers spill inside the loop, and every scratch reload waits for ALL loads in flight
-#endif
 #ifndef FL_ICP_NBQ
 #define FL_ICP_NBQ 4              // organised search: candidate positions fetched per batch (4 VGPRs each)
 #endif
@@ -942,8 +937,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
-        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  (FL_ICP_PIPE=1
-        // software-pipelines the staging one step ahead through registers; measured slower, see the macro.)
+        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  (Fetching the next
+        // step's window ahead of time -- through registers, or by LDS-DMA into a second buffer -- measured no faster: the
+        // phase is bound by VALU issue, not by the staging round trip; profiles/README.md.)
         const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         constexpr int NST = FL_ICP_NST;                             // float4 registers per lane that hold a window on its way to LDS
         constexpr int CAPL = (int)(sizeof(S.prod) / 16) / NW;       // points a wave's share of the chain tiles holds
@@ -1005,9 +1001,6 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         };
         float4 R[NST];
         Win wc;
-#if FL_ICP_PIPE
-        Win wn;
-#endif
         int sb = wv * 64;
         int i_c = ld_u32(perm, min(sb + lane, last_s));
         int i_n = ld_u32(perm, min(sb + stride + lane, last_s));
@@ -1015,24 +1008,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
         float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
         auto queryable_at = [&](int s, const F3 &q) { return s + lane < n_model && thr >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z); };
-#if FL_ICP_PIPE
-        if (sb < n_model) {
-          make_window(q_c, b_c, queryable_at(sb, q_c), wc);
-          if (wc.any && wc.staged) issue_stage(wc, R);
-        }
-#endif
         for (; sb < n_model; sb += stride) {
-#if FL_ICP_PIPE
-          if (wc.any && wc.staged) write_stage(wc, R);     // (waits for the loads issued one step ago)
-          const bool have_next = sb + stride < n_model;
-          if (have_next) {
-            make_window(q_n, b_n, queryable_at(sb + stride, q_n), wn);
-            if (wn.any && wn.staged) issue_stage(wn, R);
-          }
-#else
           make_window(q_c, b_c, queryable_at(sb, q_c), wc);
           if (wc.any && wc.staged) { issue_stage(wc, R); write_stage(wc, R); }
-#endif
           const F3 q_nn = ld3_u32(mod, i_nn);
           const float b_nn = ld_u32(bnd, i_nn);
           const int i_nnn = ld_u32(perm, min(sb + 3 * stride + lane, last_s));
@@ -1069,9 +1047,6 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             ++kept;
             if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
           }
-#if FL_ICP_PIPE
-          wc = wn;
-#endif
           i_c = i_n; q_c = q_n; b_c = b_n;
           i_n = i_nn; q_n = q_nn; b_n = b_nn;
           i_nn = i_nnn;

@@ -118,6 +118,8 @@ struct fl_detector {
 
   // device tables
   FlScanHdr *d_scan_hdr = nullptr;       // n_pyr * M
+  int2 *d_scan_items = nullptr;          // (pyramid g, 1024-position chunk) pairs that have positions to scan: k_scan's work list
+  int n_scan_items = 0;
   uint32_t *d_scan_off = nullptr;
   FlFineHdr *d_fine_hdr = nullptr;       // n_pyr * (L-1) * M, index (g*(L-1)+l)*M+m
   FlFineFeat *d_fine_feat = nullptr;

@@ -286,6 +286,8 @@ int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_strid
 // templates and are served from L2; the feature tables are the only per-template HBM stream.
 struct ScanArgs {
   const FlScanHdr *hdr;
+  const int2 *items;         // work list: (pyramid, chunk)
+  int n_items;
   const uint32_t *offs;
   const uint8_t *enabled;    // per pyramid: class selected by match()'s class_ids (linemod.cpp:1418-1434)
   uint8_t *ws;               // frame workspace base
@@ -320,8 +322,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
   const int frame = xcd + 8 * (q / a.bpf);
   if (frame >= a.n_frames) return;
   const int item = __builtin_amdgcn_readfirstlane((q % a.bpf) * 4 + wave);
-  if (item >= a.n_pyr * a.nchunks) return;
-  const int g = item / a.nchunks, chunk = item - g * a.nchunks;
+  if (item >= a.n_items) return;
+  const int2 gc = a.items[item];
+  const int g = __builtin_amdgcn_readfirstlane(gc.x), chunk = __builtin_amdgcn_readfirstlane(gc.y);
   if (!a.enabled[g]) return;                             // wave-uniform: matchClass is not called for this class
   uint8_t *ws = a.ws + (size_t)frame * a.ws_stride;
   const int j0 = chunk * 1024 + lane * 16;
@@ -823,7 +826,9 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.dbg = dbg;
     a.dbg_first = dbg_first;
     a.dbg_count = dbg_count;
-    const int items = det->n_pyr * a.nchunks;
+    a.items = det->d_scan_items;
+    a.n_items = det->n_scan_items;
+    const int items = det->n_scan_items;
     if (items > 0) {
       a.bpf = (items + 3) / 4;
       a.n_frames = n_frames;
