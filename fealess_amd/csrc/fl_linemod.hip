@@ -348,6 +348,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
     // The extra 4 bytes are the next lane's first dword: one DPP wave shift instead of a second vector load; lane 63's
     // come from a wave-uniform address, i.e. a scalar load.
     const unsigned lm_mis = (unsigned)(size_t)lm_u & 3u;  // same for every lane (lane * 16): keep it a scalar
+    // Only the lanes whose 16 positions start below template_positions have anything to add (P = 831 of the 1024 positions
+    // of a chunk for a 160-pixel template at VGA level 1: 52 of 64 lanes); one more lane stays on because its first dword is
+    // the previous lane's bytes 16..19.  The condition is a contiguous lane range, i.e. one EXEC mask around the whole loop --
+    // not a select per load (measured in round 1: that serialised the eight loads in flight) -- and the masked lanes' loads
+    // are simply not issued: 19 % less L2 traffic.
+    const int lanes_on = min(64, ((h.P - chunk * 1024 + 15) >> 4) + 1);
+    if (lane < lanes_on)
     for (int k = 0; k < h.n_pad; k += 8) {
       uint4 v[8];
       uint32_t e[8];
