@@ -46,6 +46,7 @@
 
 #define ICP_BS_SMALL 256
 #define ICP_BS_WIDE 1024
+#define ICP_DT 512                 // terms per block of the deferred dist_mean chain (two float4 per lane of the chain wave)
 #ifdef FL_ICP_PHASES
 #define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
 #else
@@ -75,6 +76,10 @@
 #define FL_ICP_NST 6              // organised search: a staged window travels through up to 6 float4 registers per lane (the whole LDS
                                   // share of the wave: 367 points; 4 -> 20.95 vs 21.59 ms per 2048 frames, more windows scanned from L2)
 #endif
+#ifndef FL_ICP_SPEC
+#define FL_ICP_SPEC 1             // parity mode, organised search: the next iteration's search runs while the chain wave adds dist_mean
+                                  // (1: in the 1024-thread kernel, 2: in both, 0: off)
+#endif
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
@@ -87,11 +92,14 @@
 //                     with index NN_IDX_NONE where the pixel was dropped by the paired compaction
 //   nn     n x i32    nearest reference index j of model point i (kept pair: j, dropped: -1)
 //   bnd    n x f32    upper bound on the distance from model point i to its nearest reference point
+//   nd     n x f32    organised search, parity mode: squared distance to nn[i] (the search runs ahead of the threshold it is
+//                     compared with, see "Search ahead of the distance chain")
+//   dterm  n x f32    parity mode: the terms of getL2distClouds' dist_mean chain, index order (0 for a dropped pair)
 //   perm   n x i32    organised search: model indices in 8x8-pixel tile order
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid (grid search)
 //   nrm   n x 3 f32   unit normals of the reference cloud, index order (FL_ICP_POINT_TO_PLANE only; 0 = unknown)
 struct IcpWsLayout {
-  size_t ref, mod, sref, nn, bnd, perm, cell_start, cell_cur, nrm, total;
+  size_t ref, mod, sref, nn, bnd, nd, dterm, perm, cell_start, cell_cur, nrm, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -105,6 +113,8 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.sref = o; o = al256(o + 16 * (nn + 1));
   L.nn = o; o = al256(o + 4 * nn);
   L.bnd = o; o = al256(o + 4 * nn);
+  L.nd = o; o = al256(o + 4 * nn);
+  L.dterm = o; o = al256(o + 4 * nn + 4 * ICP_DT);     // read in whole blocks of ICP_DT terms
   L.perm = o; o = al256(o + 4 * nn);
   L.cell_start = o; o = al256(o + 4 * ((size_t)L.ncell_max + 1));
   L.cell_cur = o; o = al256(o + 4 * (size_t)L.ncell_max);
@@ -173,6 +183,9 @@ struct IcpSharedT {
   float R[9], T[3], Ropt[9], Topt[3];
   float dist_mean, dist_diff, px, thr;
   int iter, n_corr, go, ok;
+  int cnt, inl;                          // deferred dist_mean chain: valid pairs / inliers of the terms in dterm[]
+  int stop;                              // the chain wave found the loop over: the search running ahead is abandoned
+  int a1_next;                           // organised search: next unclaimed query (64 per step)
   float xmin, ymin, inv_c;
   int GX, GY, nsorted;
   float sums[16];
@@ -185,6 +198,7 @@ struct IcpSharedT {
   // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords) of row r of tile b
   alignas(16) float prod[2][15][TS];
   alignas(16) float dtile[2][TQ];
+  alignas(16) float dchain[2][ICP_DT];   // the deferred dist_mean chain's staging (chain wave only)
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
 #endif
@@ -398,6 +412,36 @@ __device__ __forceinline__ float chain_tile(const float *col, int rows, float ac
   }
   for (int r = nb << 4; r < rows; ++r) acc += col[r];
   return acc;
+}
+
+// The deferred dist_mean chain (executed by ONE wave, all 64 lanes enter): dterm[0 .. n) added strictly in order by lane 0.
+// The wave streams the terms from HBM ICP_DT at a time (two coalesced float4 per lane, the next block in flight while
+// this one is added) through its own LDS buffer `buf` (2 x ICP_DT floats); the array is padded to whole blocks.
+template <int NBUF>
+__device__ __forceinline__ float chain_deferred(const float *__restrict__ dterm, float (*buf)[ICP_DT], int n)
+{
+  const int lane = threadIdx.x & 63;
+  const int nblk = (n + ICP_DT - 1) / ICP_DT;
+  float acc = 0.0f;
+  float4 r0, r1;
+  if (nblk > 0) {
+    r0 = *(const float4 *)(dterm + 4 * lane);
+    r1 = *(const float4 *)(dterm + 256 + 4 * lane);
+  }
+  for (int b = 0; b < nblk; ++b) {
+    float *dst = buf[b & 1];
+    *(float4 *)(dst + 4 * lane) = r0;
+    *(float4 *)(dst + 256 + 4 * lane) = r1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (b + 1 < nblk) {
+      r0 = *(const float4 *)(dterm + (size_t)(b + 1) * ICP_DT + 4 * lane);
+      r1 = *(const float4 *)(dterm + (size_t)(b + 1) * ICP_DT + 256 + 4 * lane);
+    }
+    if (lane == 0) acc = chain_tile<NBUF>(dst, min(ICP_DT, n - b * ICP_DT), acc);
+  }
+  return acc;                                            // lane 0's value is the sum
 }
 
 // uniform base + 32-bit unsigned byte offset: one VGPR per address (global_load ... v_off, s[base]) instead of a
@@ -731,11 +775,14 @@ __device__ __forceinline__ unsigned long long org_scan(F fetch, int RS, int ou, 
 // Also maintains bnd[i], an upper bound on the distance from model point i to SOME reference point: the index pair
 // before the first iteration (Ropt == nullptr), afterwards the bound grows by how far point i moved (the search
 // replaces it by the distance it found).
-template <int MODE, class SH>
-__device__ __forceinline__ void l2dist_phase(SH &S, float *mod, const float *ref, float *bnd, int n, float thr,
+// DEFER (parity mode, organised search): the terms go to dterm[] in HBM instead of LDS tiles and are NOT added here;
+// every thread produces, the valid / inlier counts are left in S.cnt / S.inl, and the chain wave adds the terms later
+// (chain_deferred) while the other waves already search for the next iteration.
+template <int MODE, bool DEFER, class SH>
+__device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *ref, float *bnd, float *dterm, int n, float thr,
                                              const float *Ropt, const float *Topt)
 {
-  constexpr bool parity = MODE == FL_ICP_PARITY;
+  constexpr bool parity = MODE == FL_ICP_PARITY && !DEFER;   // chains in this phase
   constexpr int TQ = parity ? SH::TQ : SH::BS;           // rows per tile: wave 0 only chains in parity mode
   const int slot = parity ? SH::producer_slot() : (int)threadIdx.x;
   int counter = 0, inl = 0;
@@ -797,6 +844,7 @@ __device__ __forceinline__ void l2dist_phase(SH &S, float *mod, const float *ref
         }
       }
       if (parity) S.dtile[t & 1][slot] = term;            // non-inliers add an exact +0.0f
+      if (DEFER && i < n) dterm[i] = term;
     } else if (t > 0 && threadIdx.x == 0) {
       acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
     }
@@ -807,6 +855,17 @@ __device__ __forceinline__ void l2dist_phase(SH &S, float *mod, const float *ref
     acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
   counter = block_sum_int(S, counter);
   inl = block_sum_int(S, inl);
+  if (DEFER) {
+    // An upper bound of the dist_mean the chain will produce, from a parallel fp64 sum P of the same terms: the float32
+    // chain c of n non-negative terms satisfies c <= (1 + n u) E, u = 2^-24, E the exact sum (and P = E to 1e-12), and
+    // the division adds one rounding.
+    block_sum_double<1>(S, dsum);
+    if (threadIdx.x == 0) { S.cnt = counter; S.inl = inl; }
+    const double P = S.dsum[0][0];
+    __syncthreads();
+    if (counter <= 0) return INFINITY;                   // dist_mean = FLT_MAX
+    return (float)(P / (double)inl * (1.0 + 1.3e-7 * (double)n + 1.0e-6)) * 1.000001f;      // 0 inliers: NaN, as dist_mean will be
+  }
   float dm;
   if (parity) {
     if (threadIdx.x == 0) S.sums[0] = acc;
@@ -827,6 +886,7 @@ __device__ __forceinline__ void l2dist_phase(SH &S, float *mod, const float *ref
     }
   }
   __syncthreads();
+  return 0.0f;
 }
 
 // ---- icpCloudToCloud_Ex (ICP.cpp:617-809) --------------------------------------------------------
@@ -841,6 +901,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   float4 *sref = (float4 *)(wsb + L.sref);
   int *nn = (int *)(wsb + L.nn);
   float *bnd = (float *)(wsb + L.bnd);
+  float *nd = (float *)(wsb + L.nd), *dterm = (float *)(wsb + L.dterm);
   const int *perm = (const int *)(wsb + L.perm);
   const float *nrm = (const float *)(wsb + L.nrm);
   int *cell_start = (int *)(wsb + L.cell_start), *cell_cur = (int *)(wsb + L.cell_cur);
@@ -882,15 +943,208 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     S.dist_diff = FLT_MAX;
   }
   __syncthreads();
-  l2dist_phase<MODE>(S, mod, ref, bnd, n_model, FLT_MAX, nullptr, nullptr);             // :670
+  // Search ahead of the distance chain (parity mode, organised search).  getL2distClouds' dist_mean is one float32 chain over
+  // all points: alone it costs a quarter of an iteration during which every wave but one waits.  So the terms are written
+  // to dterm[] (l2dist_phase<DEFER>), and while the chain wave adds them the other waves already run PointsCorresponding for
+  // the NEXT iteration -- against a threshold that is not known yet.  It needs none: the search radius of a point is
+  // min(bnd[i], r_lim) with r_lim >= sqrt(3 dist_mean) whatever the chain will find (l2dist_phase returns an upper bound
+  // of its result, a fraction of a percent above a parallel sum of the same terms), the exact neighbour and its distance
+  // are stored (nn[], nd[]), and `d <= 3 dist_mean` (:268) is applied where the pairs are consumed.  A wider radius only
+  // visits more pixels; the neighbour found is the same.  If the chain ends the loop, the search is abandoned (S.stop).
+  // Only the 1024-thread workgroup (batches that leave CUs idle) does this: with four 256-thread workgroups per CU the
+  // other workgroups already fill the chain's shadow, and the extra traffic (dterm, nd) costs 7 % there (profiles/README.md).
+  constexpr bool SPEC = (FL_ICP_SPEC == 2 || (FL_ICP_SPEC == 1 && BS >= ICP_BS_WIDE)) && MODE == FL_ICP_PARITY && ORG;
+  float mean_ub = l2dist_phase<MODE, SPEC>(S, mod, ref, bnd, dterm, n_model, FLT_MAX, nullptr, nullptr);             // :670
+  int pending = SPEC ? 1 : 0;                            // 1: the initial distances await their chain, 2: an iteration's
+  bool have_nn = false;                                  // nn[] / nd[] hold the neighbours of the current model cloud
+  float old_mean = 0.0f;                                 // dist_mean before the pending distances (pending == 2)
+
+  // ---- organised search: PointsCorresponding (:193-279) for every model point, exact 1-NN within min(bnd[i], r_lim) ----
+  // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  Steps are claimed from a
+  // workgroup counter (S.a1_next, reset by the caller) in parity mode, four steps ahead of the one being scanned, so that
+  // the loads of the next steps (perm -> mod, bnd) are in flight and a wave that joins late (the chain wave) simply takes
+  // what is left.
+  // (Fetching the next step's window ahead of time -- through registers, or by LDS-DMA into a second buffer -- measured no
+  // faster: the phase is bound by VALU issue, not by the staging round trip; profiles/README.md.)
+  // found(active, i, qx, qy, qz, j, d): j = -1, d = NaN when no reference point lies within the radius.
+  auto org_search = [&](const float r_lim, const bool poll_stop, auto &&found) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    constexpr int NST = FL_ICP_NST;                             // float4 registers per lane that hold a window on its way to LDS
+    constexpr int CAPL = (int)(sizeof(S.prod) / 16) / NW;       // points a wave's share of the chain tiles holds
+    constexpr int CAPW = CAPL < 64 * NST ? CAPL : 64 * NST;     // points a wave stages: larger unions are scanned from L2
+    float4 *stage = (float4 *)&S.prod[0][0][0] + wv * CAPW;
+    const float4 *refimg = sref;
+    const int last_s = n_model - 1;
+    struct Win {
+      int u_lo, u_hi, v_lo, v_hi;        // this lane's window (crop pixels); a lane without one looks at (U0, V0)
+      int U0, V0, W, area, maxw, maxh;   // wave-uniform: union rectangle and the largest lane window
+      bool any, staged;                  // wave-uniform: some lane has a window; the union fits the LDS share
+    };
+    auto make_window = [&](const F3 &q, float b, bool queryable, Win &w) {
+      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
+      if (queryable) org_window(og, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_lim)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_lim
+      const bool some = u_lo <= u_hi;
+      const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
+      w.any = U1 >= U0;
+      w.U0 = U0; w.V0 = 0; w.W = 1; w.area = 0; w.maxw = 0; w.maxh = 0; w.staged = false;
+      if (w.any) {
+        const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
+        w.maxw = wave_max_i(u_hi - u_lo + 1);
+        w.maxh = wave_max_i(v_hi - v_lo + 1);
+        if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one staged point: a real
+                                                             // reference point beyond their radius, which the gate drops
+        w.V0 = V0;
+        w.W = U1 - U0 + 1;
+        w.area = w.W * (V1 - V0 + 1);
+        w.staged = w.area <= CAPW;
+      }
+      w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
+    };
+    auto issue_stage = [&](const Win &w, float4 (&R)[NST]) {
+      // slot k = lane + 64 t holds point (k / W, k % W) of the union rectangle: one division (by reciprocal: exact for
+      // k < 2^20, k + 0.5 keeps clear of the integers) for t = 0, then (row, col) advance by 64 slots incrementally;
+      // all products fit 24 bits
+      const float invW = 1.0f / (float)w.W;
+      int row = (int)(((float)lane + 0.5f) * invW), col = lane - row * w.W;
+      const int drow = (int)(64.5f * invW), dcol = 64 - drow * w.W;      // 64 = drow * W + dcol (wave-uniform)
+      int idx = (int)__umul24((unsigned)(w.V0 + row), (unsigned)og.cw) + w.U0 + col;
+      const int didx = (int)__umul24((unsigned)drow, (unsigned)og.cw) + dcol;
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        if (lane + 64 * j < w.area) R[j] = ld_u32(refimg, idx);
+        col += dcol;
+        idx += didx;
+        if (col >= w.W) { col -= w.W; idx += og.cw - w.W; }
+      }
+    };
+    auto write_stage = [&](const Win &w, const float4 (&R)[NST]) {
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        const int k = lane + 64 * j;
+        if (k < w.area) stage[k] = R[j];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // Steps are claimed from the workgroup counter only where a wave joins late (SPEC); the modes that keep per-thread
+    // partial sums need a fixed assignment of queries to threads to be deterministic: wave w takes steps w, w + NW, ...
+    constexpr int stride = NW * 64;
+    int static_next = wv * 64 + 4 * stride;
+    auto claim = [&](int count) {                          // `count` queries off the workgroup's list (wave-uniform result)
+      int v = 0;
+      if (lane == 0) v = atomicAdd(&S.a1_next, count);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto next_step = [&]() {
+      if (SPEC) return claim(64);
+      const int v = static_next;
+      static_next += stride;
+      return v;
+    };
+    float4 R[NST];
+    Win wc;
+    const int sdist = SPEC ? 64 : stride;
+    int sb0 = SPEC ? claim(256) : wv * 64, sb1 = sb0 + sdist, sb2 = sb0 + 2 * sdist, sb3 = sb0 + 3 * sdist;
+    int i_c = ld_u32(perm, min(sb0 + lane, last_s));
+    int i_n = ld_u32(perm, min(sb1 + lane, last_s));
+    int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
+    F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
+    float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
+    auto queryable_at = [&](int s, const F3 &q) { return s + lane < n_model && r_lim >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z); };
+    while (sb0 < n_model) {
+      if (poll_stop && *(volatile int *)&S.stop) break;
+      const int sb4 = next_step();
+      make_window(q_c, b_c, queryable_at(sb0, q_c), wc);
+      if (wc.any && wc.staged) { issue_stage(wc, R); write_stage(wc, R); }
+      const F3 q_nn = ld3_u32(mod, i_nn);
+      const float b_nn = ld_u32(bnd, i_nn);
+      const int i_nnn = ld_u32(perm, min(sb3 + lane, last_s));
+      const int i = i_c;
+      const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
+      const bool active = sb0 + lane < n_model;
+      const bool queryable = queryable_at(sb0, q_c);
+      int j = -1;
+      float d = NAN;
+      if (wc.any) {                                    // wave-uniform: at least one lane has a window
+#ifdef FL_ICP_PHASES
+        if (lane == 0) {
+          atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
+          atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(wc.maxw * wc.maxh));
+          atomicAdd((unsigned long long *)&S.tacc[10], wc.staged ? 0ull : 1ull);
+          atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)wc.area);
+          if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(wc.maxw * wc.maxh));
+        }
+#endif
+        unsigned long long best;
+        if (wc.staged)
+          best = org_scan([&](int idx) { return stage[idx]; }, wc.W, wc.U0, wc.V0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw, wc.maxh);
+        else
+          best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw,
+                          wc.maxh);
+        if (queryable) NN_UNPACK(best, &j, &d)
+      }
+      found(active, i, qx, qy, qz, j, d);
+      i_c = i_n; q_c = q_n; b_c = b_n;
+      i_n = i_nn; q_n = q_nn; b_n = b_nn;
+      i_nn = i_nnn;
+      sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
+    }
+  };
+  // the deferred dist_mean chain of the pending distances (chain wave), then -- every wave -- the search for the next iteration
+  auto chain_and_search = [&](const int pend, const bool want, const float r_lim, const float old_mean_) {
+    if (pend && threadIdx.x < 64) {
+      const float acc = chain_deferred<SH::CHAIN_NBUF>(dterm, S.dchain, n_model);
+      if (threadIdx.x == 0) {
+        const int counter = S.cnt, inl = S.inl;
+        float dm = acc;
+        if (counter > 0) dm /= (float)inl;               // 0/0 -> NaN ends the loop (Q9)
+        const float new_mean = counter > 0 ? dm : FLT_MAX;
+        S.px = counter > 0 ? (float)inl / (float)counter : 0.0f;
+        if (pend == 2) {
+          S.dist_diff = old_mean_ - new_mean;
+          float RT[3];                                   // :793-797
+          mat_vec(S.Ropt, S.T, RT);
+          for (int k = 0; k < 3; ++k) S.T[k] = RT[k] + S.Topt[k];
+          mat_mat(S.Ropt, S.R, S.R);
+        }
+        S.dist_mean = new_mean;
+        const bool go = (new_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);       // :684, as the loop head will find it
+        *(volatile int *)&S.stop = go ? 0 : 1;
+      }
+    }
+    if (want)
+      org_search(r_lim, true, [&](bool active, int i, float, float, float, int j, float d) {
+        if (active) {
+          nn[i] = j;
+          nd[i] = d;
+          if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
+        }
+      });
+  };
+
 
   for (;;) {
+    if (SPEC) {
+      const int it_done = __builtin_amdgcn_readfirstlane(S.iter);
+      const bool want = !have_nn && it_done >= 1 && it_done < it_thr;   // the next iteration, if there is one, searches
+      if (pending || want) {
+        const float r_lim = pending ? sqrtf(3.0f * mean_ub) * 1.00001f : sqrtf(3 * S.dist_mean);
+        if (threadIdx.x == 0) { S.a1_next = 0; S.stop = 0; }
+        __syncthreads();
+        chain_and_search(pending, want, uniform_f(r_lim), old_mean);
+        __syncthreads();                                 // dist_mean, nn[], nd[], bnd[] complete
+        TSTAMP(2);
+        if (want) have_nn = true;
+        pending = 0;
+      }
+    }
     if (threadIdx.x == 0) S.go = (S.dist_mean > dmt) && (S.dist_diff > ddt) && (S.iter < it_thr);   // :684
     __syncthreads();
     if (!S.go) break;
     // point-to-plane gates pairs at distance 3*dist_mean; the reference compares the SQUARED distance
     // with 3*dist_mean (Q9), which parity/fast keep
-    if (threadIdx.x == 0) { ++S.iter; S.thr = plane ? (3 * S.dist_mean) * (3 * S.dist_mean) : 3 * S.dist_mean; }
+    if (threadIdx.x == 0) { ++S.iter; S.thr = plane ? (3 * S.dist_mean) * (3 * S.dist_mean) : 3 * S.dist_mean; S.a1_next = 0; }
     __syncthreads();
     const int iter = __builtin_amdgcn_readfirstlane(S.iter);
     const float thr = uniform_f(S.thr);
@@ -931,126 +1185,24 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         for (int q = 0; q < 3; ++q) { ds[9 + q] += (double)m[q]; ds[12 + q] += (double)r[q]; }
       }
     };
-    if (!index_pairs) {
+    if (!index_pairs && !SPEC) {
       // Phase A1 -- PointsCorresponding (:193-279): all waves search.  bnd[i] (distance to the partner found
       // last time plus the motion since; initially the index pair) bounds the search radius, so a converging
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
-        // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  (Fetching the next
-        // step's window ahead of time -- through registers, or by LDS-DMA into a second buffer -- measured no faster: the
-        // phase is bound by VALU issue, not by the staging round trip; profiles/README.md.)
-        const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        constexpr int NST = FL_ICP_NST;                             // float4 registers per lane that hold a window on its way to LDS
-        constexpr int CAPL = (int)(sizeof(S.prod) / 16) / NW;       // points a wave's share of the chain tiles holds
-        constexpr int CAPW = CAPL < 64 * NST ? CAPL : 64 * NST;     // points a wave stages: larger unions are scanned from L2
-        float4 *stage = (float4 *)&S.prod[0][0][0] + wv * CAPW;
-        const float4 *refimg = sref;
-        const int last_s = n_model - 1, stride = NW * 64;
-        struct Win {
-          int u_lo, u_hi, v_lo, v_hi;        // this lane's window (crop pixels); a lane without one looks at (U0, V0)
-          int U0, V0, W, area, maxw, maxh;   // wave-uniform: union rectangle and the largest lane window
-          bool any, staged;                  // wave-uniform: some lane has a window; the union fits the LDS share
-        };
-        auto make_window = [&](const F3 &q, float b, bool queryable, Win &w) {
-          int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
-          if (queryable) org_window(og, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_thr)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_thr
-          const bool some = u_lo <= u_hi;
-          const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
-          w.any = U1 >= U0;
-          w.U0 = U0; w.V0 = 0; w.W = 1; w.area = 0; w.maxw = 0; w.maxh = 0; w.staged = false;
-          if (w.any) {
-            const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
-            w.maxw = wave_max_i(u_hi - u_lo + 1);
-            w.maxh = wave_max_i(v_hi - v_lo + 1);
-            if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one staged point: a real
-                                                                 // reference point beyond their radius, which the gate drops
-            w.V0 = V0;
-            w.W = U1 - U0 + 1;
-            w.area = w.W * (V1 - V0 + 1);
-            w.staged = w.area <= CAPW;
-          }
-          w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
-        };
-        auto issue_stage = [&](const Win &w, float4 (&R)[NST]) {
-          // slot k = lane + 64 t holds point (k / W, k % W) of the union rectangle: one division (by reciprocal: exact for
-          // k < 2^20, k + 0.5 keeps clear of the integers) for t = 0, then (row, col) advance by 64 slots incrementally;
-          // all products fit 24 bits
-          const float invW = 1.0f / (float)w.W;
-          int row = (int)(((float)lane + 0.5f) * invW), col = lane - row * w.W;
-          const int drow = (int)(64.5f * invW), dcol = 64 - drow * w.W;      // 64 = drow * W + dcol (wave-uniform)
-          int idx = (int)__umul24((unsigned)(w.V0 + row), (unsigned)og.cw) + w.U0 + col;
-          const int didx = (int)__umul24((unsigned)drow, (unsigned)og.cw) + dcol;
-#pragma unroll
-          for (int j = 0; j < NST; ++j) {
-            if (lane + 64 * j < w.area) R[j] = ld_u32(refimg, idx);
-            col += dcol;
-            idx += didx;
-            if (col >= w.W) { col -= w.W; idx += og.cw - w.W; }
-          }
-        };
-        auto write_stage = [&](const Win &w, const float4 (&R)[NST]) {
-#pragma unroll
-          for (int j = 0; j < NST; ++j) {
-            const int k = lane + 64 * j;
-            if (k < w.area) stage[k] = R[j];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        float4 R[NST];
-        Win wc;
-        int sb = wv * 64;
-        int i_c = ld_u32(perm, min(sb + lane, last_s));
-        int i_n = ld_u32(perm, min(sb + stride + lane, last_s));
-        int i_nn = ld_u32(perm, min(sb + 2 * stride + lane, last_s));
-        F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
-        float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
-        auto queryable_at = [&](int s, const F3 &q) { return s + lane < n_model && thr >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z); };
-        for (; sb < n_model; sb += stride) {
-          make_window(q_c, b_c, queryable_at(sb, q_c), wc);
-          if (wc.any && wc.staged) { issue_stage(wc, R); write_stage(wc, R); }
-          const F3 q_nn = ld3_u32(mod, i_nn);
-          const float b_nn = ld_u32(bnd, i_nn);
-          const int i_nnn = ld_u32(perm, min(sb + 3 * stride + lane, last_s));
-          const int i = i_c;
-          const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
-          const bool active = sb + lane < n_model;
-          const bool queryable = queryable_at(sb, q_c);
-          int j = -1;
-          float d = NAN;
-          if (wc.any) {                                    // wave-uniform: at least one lane has a window
-#ifdef FL_ICP_PHASES
-            if (lane == 0) {
-              atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
-              atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(wc.maxw * wc.maxh));
-              atomicAdd((unsigned long long *)&S.tacc[10], wc.staged ? 0ull : 1ull);
-              atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)wc.area);
-              if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(wc.maxw * wc.maxh));
+        if (!SPEC)
+          org_search(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
+            const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
+            if (active) {
+              nn[i] = keep ? j : -1;
+              if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
             }
-#endif
-            unsigned long long best;
-            if (wc.staged)
-              best = org_scan([&](int idx) { return stage[idx]; }, wc.W, wc.U0, wc.V0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw, wc.maxh);
-            else
-              best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw,
-                              wc.maxh);
-            if (queryable) NN_UNPACK(best, &j, &d)
-          }
-          const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
-          if (active) {
-            nn[i] = keep ? j : -1;
-            if (j >= 0) bnd[i] = sqrt_upper(d);               // else: the old partner is still within the old bound
-          }
-          if (keep) {
-            ++kept;
-            if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
-          }
-          i_c = i_n; q_c = q_n; b_c = b_n;
-          i_n = i_nn; q_n = q_nn; b_n = b_nn;
-          i_nn = i_nnn;
-        }
+            if (keep) {
+              ++kept;
+              if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
+            }
+          });
       } else {
         const NnGrid G = nn_grid(S);
         int i = threadIdx.x;
@@ -1092,8 +1244,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       float m1[3] = {0.f, 0.f, 0.f}, r1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
       if (slot >= 0) {
         const int i0 = slot, i1 = TQ + slot;
-        if (i0 < rows) { j1 = ld_u32(nn, i0); { const F3 v3_ = ld3_u32(mod, i0); m1[0] = v3_.x; m1[1] = v3_.y; m1[2] = v3_.z; } }
-        if (i1 < rows) { j2 = ld_u32(nn, i1); { const F3 v3_ = ld3_u32(mod, i1); m2[0] = v3_.x; m2[1] = v3_.y; m2[2] = v3_.z; } }
+        // SPEC: nn[] holds the neighbour whatever its distance; the pair is kept if d <= dist_thr (:268; NaN = none found)
+        if (i0 < rows) { j1 = ld_u32(nn, i0); if (SPEC && !(ld_u32(nd, i0) <= thr)) j1 = -1; { const F3 v3_ = ld3_u32(mod, i0); m1[0] = v3_.x; m1[1] = v3_.y; m1[2] = v3_.z; } }
+        if (i1 < rows) { j2 = ld_u32(nn, i1); if (SPEC && !(ld_u32(nd, i1) <= thr)) j2 = -1; { const F3 v3_ = ld3_u32(mod, i1); m2[0] = v3_.x; m2[1] = v3_.y; m2[2] = v3_.z; } }
         const int g = max(j1, 0);
         { const F3 v3_ = ld3_u32(ref, g); r1[0] = v3_.x; r1[1] = v3_.y; r1[2] = v3_.z; }
       }
@@ -1102,13 +1255,15 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           const int i3 = min((t + 2) * TQ + slot, rows - 1);     // clamped: unused past the end
           const bool in3 = (t + 2) * TQ + slot < rows;
           int j3 = ld_u32(nn, i3);
+          const float d3 = SPEC ? ld_u32(nd, i3) : 0.0f;
           const F3 m3v = ld3_u32(mod, i3);
           const float m3[3] = {m3v.x, m3v.y, m3v.z};
-          j3 = in3 ? j3 : -1;
+          j3 = in3 && (!SPEC || d3 <= thr) ? j3 : -1;
           const int g = max(j2, 0);
           const F3 r2v = ld3_u32(ref, g);
           const float r2[3] = {r2v.x, r2v.y, r2v.z};
           const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f: (+0) * (+0)
+          if (SPEC && have) ++kept;
           float (*tile)[SH::TS] = S.prod[t & 1];
           float mm[3], rr[3];
 #pragma unroll
@@ -1269,10 +1424,15 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     float Ro[9], To[3];
     for (int k = 0; k < 9; ++k) Ro[k] = S.Ropt[k];
     for (int k = 0; k < 3; ++k) To[k] = S.Topt[k];
-    const float old_mean = S.dist_mean;
+    old_mean = S.dist_mean;
     __syncthreads();
-    l2dist_phase<MODE>(S, mod, ref, bnd, n_model, 3 * old_mean, Ro, To);           // :756, :778-780
+    mean_ub = l2dist_phase<MODE, SPEC>(S, mod, ref, bnd, dterm, n_model, 3 * old_mean, Ro, To);           // :756, :778-780
     TSTAMP(5);
+    if (SPEC) {                                          // the chain, dist_diff and the pose update follow at the loop head
+      pending = 2;
+      have_nn = false;
+      continue;
+    }
     if (threadIdx.x == 0) {
       S.dist_diff = old_mean - S.dist_mean;
       float RT[3];                                       // :793-797
@@ -1695,16 +1855,18 @@ static int icp_launch_one(fl_context *ctx, K kern, int n_jobs, const IcpArgs &a)
   return FL_OK;
 }
 // Workgroup width by batch size: with no more jobs than CUs every job runs alone on its CU whatever its width, so it
-// gets the 1024-thread kernel (FL_ICP_WIDE=0/1 forces one or the other: dev knob)
+// gets the 1024-thread kernel; two rounds of it still beat two 256-thread workgroups per CU (measured, ICP ms per launch,
+// 1024- vs 256-thread: 256 jobs 3.6 / 6.8, 384: 6.4 / 7.2, 512: 6.8 / 7.7, 768: 10.0 / 8.9, 1024: 13.2 / 11.1).
+// FL_ICP_WIDE=0/1 forces one or the other (dev knob)
 static bool icp_wide(fl_context *ctx, int n_jobs)
 {
-  static const char *env = getenv("FL_ICP_WIDE");
+  const char *env = getenv("FL_ICP_WIDE");
   if (env && env[0] == '0') return false;
   if (env && env[0] == '1') return true;
   int cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  return n_jobs <= cus;
+  return n_jobs <= 2 * cus;
 }
 template <int MODE>
 static int icp_launch_mode(fl_context *ctx, int n_jobs, const IcpArgs &a)

@@ -48,8 +48,16 @@ def test_depth_to_3d_bit_exact(ctx, oracle, w, h, K):
     assert np.array_equal(_bits(np.nan_to_num(got)), _bits(np.nan_to_num(exp)))
 
 
+@pytest.fixture(params=["1024", "256"])
+def width(request, monkeypatch):
+    """Both builds of the ICP kernels: the library picks the 1024-thread workgroup for batches of up to two jobs per CU (with the
+    search running ahead of the dist_mean chain) and the 256-thread one beyond; FL_ICP_WIDE forces either for any batch."""
+    monkeypatch.setenv("FL_ICP_WIDE", "1" if request.param == "1024" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("seed,n,it", [(1, 6000, 20), (2, 1500, 10), (3, 12000, 6)])
-def test_icp_parity_mode_matches_oracle32(ctx, oracle, seed, n, it):
+def test_icp_parity_mode_matches_oracle32(ctx, oracle, seed, n, it, width):
     ref, model = _clouds(seed, n)
     got = ctx.icp_cloud_to_cloud_ex(ref, model, it, 0.0, -3.0e38, L.FL_ICP_PARITY)
     exp = oracle.icp(ref, model, it, 0.0, -3.0e38, accum64=False, use_kdtree=True)
@@ -62,7 +70,7 @@ def test_icp_parity_mode_matches_oracle32(ctx, oracle, seed, n, it):
     assert _bits(got["dist_mean"]) == _bits(exp["dist_mean"])
 
 
-def test_icp_default_thresholds_early_exit(ctx, oracle):
+def test_icp_default_thresholds_early_exit(ctx, oracle, width):
     ref, model = _clouds(4, 5000)
     got = ctx.icp_cloud_to_cloud_ex(ref, model, 10, 0.5, 0.01, L.FL_ICP_PARITY)
     exp = oracle.icp(ref, model, 10, 0.5, 0.01)
@@ -83,7 +91,7 @@ def test_icp_fast_mode_close_to_fp64_yardstick(ctx, oracle):
     print("noise floor |ref32 - exact64| R", np.abs(truth["R"] - exp["R"]).max(), "T", np.abs(truth["T"] - exp["T"]).max())
 
 
-def test_icp_edge_cases(ctx, oracle):
+def test_icp_edge_cases(ctx, oracle, width):
     ref, model = _clouds(6, 200)
     r = ctx.icp_cloud_to_cloud_ex(ref[:2], model[:2], 5)
     assert r["dist_mean"] == -1.0 and not r["R"].any() and r["iters"] == 0      # < 3 points (ICP.cpp:633-638)
@@ -113,7 +121,7 @@ def test_icp_unequal_sizes(ctx, oracle):
     assert np.array_equal(_bits(got["R"]), _bits(exp["R"])) and np.array_equal(_bits(got["T"]), _bits(exp["T"]))
 
 
-def test_detection_matches_oracle(ctx, oracle):
+def test_detection_matches_oracle(ctx, oracle, width):
     R, t = synth.object_pose(tx=10, ty=-5, tz=660)
     scene, _, _ = synth.render(640, 480, R, t, seed=3)
     R2 = synth.rot_z(0.03) @ R
@@ -140,7 +148,7 @@ def test_detection_matches_oracle(ctx, oracle):
 
 
 @pytest.mark.parametrize("seed", [3, 8])
-def test_recognition_matches_oracle(ctx, oracle, seed):
+def test_recognition_matches_oracle(ctx, oracle, seed, width):
     sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=seed, n_views=5,
                                  n_random=30)
     det = api.Detector(ctx, 2, [5, 8])
