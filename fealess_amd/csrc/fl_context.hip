@@ -347,7 +347,10 @@ static int layout_workspace(fl_detector *det, int cap)
     return fl_set_error(ctx, FL_ERR_HIP, "frame workspaces: %zu MB for %d frames with %d candidates each", (det->ws_stride * (size_t)det->max_batch) >> 20,
                         det->max_batch, cap);
   }
-  FL_HIP(ctx, hipMemset(det->d_ws, 0, det->ws_stride * (size_t)det->max_batch));
+  // on the context's stream (it is non-blocking: a null-stream hipMemset is not ordered against it and would still be
+  // zeroing the workspace while the replay after fl_grow_candidates fills it), and finished before anything else starts
+  FL_HIP(ctx, hipMemsetAsync(det->d_ws, 0, det->ws_stride * (size_t)det->max_batch, ctx->stream));
+  FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return FL_OK;
 }
 

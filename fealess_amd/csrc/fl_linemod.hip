@@ -301,6 +301,7 @@ struct ScanArgs {
   int dbg_first, dbg_count;
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld16(const uint8_t *p)
 {
   uint4 v;
@@ -339,7 +340,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
     if (chunk * 1024 >= h.P) continue;                  // wave-uniform; lanes past P load along (masked below): the
                                                        // next lane's first dword is this lane's bytes 16..19
     const uint8_t *lm_u = ws + a.lm_off[m] + chunk * 1024;   // lane 0's bytes: wave-uniform
-    const uint8_t *lm = lm_u + lane * 16;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    // descriptor over the frame's linear memories from 4 bytes below this chunk on (scalar offsets stay positive)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(lm_u - 4), 0, 0x7FFFFFFF, 0x00020000);
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const uint32_t *offs = a.offs + h.off_begin;
     // A feature's 16 bytes start at an arbitrary byte.  A byte-aligned 16-byte load costs ~2.4x a 4-byte aligned one
@@ -363,8 +366,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
       for (int u = 0; u < 8; ++u) {
         const unsigned off = offs[k + u];
         mis[u] = (lm_mis + off) & 3u;
-        const uint8_t *pa = lm + off - mis[u];             // 4-byte aligned
-        v[u] = *(const uint4 *)__builtin_assume_aligned(pa, 4);
+        // buffer_load ... v_lane_off, s[rsrc], s_feature_off offen: the lane's byte offset is one loop-invariant VGPR and the
+        // feature's offset a scalar operand -- no per-lane 64-bit address arithmetic (it was 2 of the 10 VALU instructions
+        // per feature)
+        const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, off - mis[u] + 4u, 0);   // 4-byte aligned
+        v[u] = make_uint4(ld.x, ld.y, ld.z, ld.w);
         const uint32_t tail = *(const uint32_t *)__builtin_assume_aligned(lm_u + off - mis[u] + 1024, 4);
         e[u] = (uint32_t)__builtin_amdgcn_update_dpp((int)tail, (int)v[u].x, 0x130, 0xF, 0xF, false);   // wave_shl:1
       }
