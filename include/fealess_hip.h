@@ -14,7 +14,10 @@
  * bound to one HIP device; calls on one context must be serialised by the caller (the
  * reference's CObjRecoLmICP is not thread-safe either, obj_reco_lmicp.h:37-51).  Work is queued
  * on the context's stream; functions that return results through host pointers synchronise
- * that stream before returning, functions that write device pointers do not.
+ * that stream before returning, functions that write device pointers do not.  The stream is
+ * non-blocking (not ordered against the null stream): device buffers handed in (FL_MEM_DEVICE
+ * frames, clouds, quantised images) must be complete when the call is made, or have been
+ * produced on the stream given to fl_context_set_stream().
  * There is NO CPU fallback: without a HIP device fl_context_create fails.
  */
 #ifndef FEALESS_HIP_H
