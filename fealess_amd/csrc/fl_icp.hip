@@ -76,6 +76,20 @@
 #define FL_ICP_NST 6              // organised search: a staged window travels through up to 6 float4 registers per lane (the whole LDS
                                   // share of the wave: 367 points; 4 -> 20.95 vs 21.59 ms per 2048 frames, more windows scanned from L2)
 #endif
+#ifndef FL_ICP_PD
+#define FL_ICP_PD 1               // chain phases, parity mode: tiles whose loads a producer thread keeps in flight (phase A2: the
+                                  // dependent gather ref[nn[i]] runs FL_ICP_PD tiles ahead, nn / mod one more; phase B: mod / ref / bnd).
+                                  // Measured at 2048 frames: 1 / 2 / 3 / 4 -> 20.93 / 20.86 / 21.04 / 20.92 ms: the chain phases do not
+                                  // wait for the producers' loads
+#endif
+#ifndef FL_ICP_SPLIT
+#define FL_ICP_SPLIT 1            // chain phases: the chain wave and the producer waves run separate loops (same barrier count), so
+                                  // the chain's register batches do not share a live range with the producers' pipeline state
+#endif
+#ifndef FL_ICP_NBUF_SMALL
+#define FL_ICP_NBUF_SMALL 2       // 16-row register batches of a chain in the 256-thread kernel (with the split loops 2 / 3 / 4 measure
+                                  // the same 20.8-20.9 ms per 2048 frames: the chains do not wait for their LDS reads either)
+#endif
 #ifndef FL_ICP_SPEC
 #define FL_ICP_SPEC 1             // parity mode, organised search: the next iteration's search runs while the chain wave adds dist_mean
                                   // (1: in the 1024-thread kernel, 2: in both, 0: off)
@@ -87,7 +101,7 @@
 // HBM layout of one frame's ICP workspace (n = capacity in points):
 //   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
 //   mod   n x 3 f32   model cloud, transformed in place every iteration
-//   sref  (n+1) x float4   grid search: reference cloud sorted by grid cell, w = original index (bit pattern);
+//   sref  (n+4) x float4   (index bits, X, Y, Z).  grid search: reference cloud sorted by grid cell, original index;
 //                     organised search: the reference IMAGE, crop pixel p -> (point, index) or a point at infinity
 //                     with index NN_IDX_NONE where the pixel was dropped by the paired compaction
 //   nn     n x i32    nearest reference index j of model point i (kept pair: j, dropped: -1)
@@ -110,7 +124,7 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.ncell_max = n + 4096;
   L.ref = o; o = al256(o + 12 * nn);
   L.mod = o; o = al256(o + 12 * nn);
-  L.sref = o; o = al256(o + 16 * (nn + 1));
+  L.sref = o; o = al256(o + 16 * (nn + 4));          // + NN_OVERRUN points at infinity behind the reference image
   L.nn = o; o = al256(o + 4 * nn);
   L.bnd = o; o = al256(o + 4 * nn);
   L.nd = o; o = al256(o + 4 * nn);
@@ -169,7 +183,7 @@ struct IcpSharedT {
   // waves that share wave 0's SIMD (waves 4, 8, 12: the SPI deals a workgroup's waves round-robin over the 4 SIMDs) out
   // of the producer role, so the chain wave has its SIMD's issue slots to itself.
   static constexpr int NPROD = NW >= 8 ? NW - NW / 4 : NW - 1;
-  static constexpr int CHAIN_NBUF = BS_ >= 1024 ? 4 : 2;
+  static constexpr int CHAIN_NBUF = BS_ >= 1024 ? 4 : FL_ICP_NBUF_SMALL;
   static constexpr int TQ = NPROD * 64;   // rows per LDS tile
   // tile row of this thread, or -1 (chain wave / idle wave)
   static __device__ __forceinline__ int producer_slot()
@@ -467,6 +481,15 @@ __device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
 // only widens the visited area; the nearest neighbour found is the same.
 __device__ __forceinline__ float sqrt_upper(float x) { return __builtin_amdgcn_sqrtf(x) * 1.000001f + 1.1e-19f; }
 
+// A searchable reference point is a float4 (index bits, X, Y, Z): the index comes FIRST so that the 64-bit key
+// (index low, d2 high) can be formed in the two registers the load put the index and X into -- X is dead once dx is
+// computed -- without a register move per candidate.
+__device__ __forceinline__ float4 nn_point(float x, float y, float z, int index) { return make_float4(__int_as_float(index), x, y, z); }
+__device__ __forceinline__ int nn_point_index(const float4 &p) { return __float_as_int(p.x); }
+#ifndef FL_ICP_BATCH_CLAMP
+#define FL_ICP_BATCH_CLAMP 1
+#endif
+#define NN_OVERRUN 3                // readable points behind the last position of a staged window / of the reference image
 #define NN_IDX_NONE 0x7fffffff      // index stored with a dropped pixel of the reference image (real indices are below it)
 
 // ---- uniform x/y grid over the reference cloud --------------------------------------------------
@@ -587,7 +610,7 @@ __device__ __forceinline__ void build_grid(SH &S, const float *ref, int n_ref, f
     const float x = p3.x, y = p3.y, z = p3.z;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
       const int slot = atomicAdd(&cell_cur[cell_of(y, S.ymin, S.inv_c, S.GY) * S.GX + cell_of(x, S.xmin, S.inv_c, S.GX)], 1);
-      sref[slot] = make_float4(x, y, z, __int_as_float(i));
+      sref[slot] = nn_point(x, y, z, i);
     }
   }
   __syncthreads();
@@ -626,11 +649,11 @@ __device__ __forceinline__ float nn_radius(float qx, float qy, float qz, float l
 #define NN_KEY_NONE 0xFFFFFFFFFFFFFFFFull
 __device__ __forceinline__ unsigned long long nn_key(float qx, float qy, float qz, const float4 &p)
 {
-  const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+  const float dx = qx - p.y, dy = qy - p.z, dz = qz - p.w;
   float d = dx * dx;                                     // cvflann::L2_Simple<float>
   d += dy * dy;
   d += dz * dz;
-  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.x);
 }
 #define NN_CONSIDER(P) { const unsigned long long key_ = nn_key(qx, qy, qz, (P)); best = key_ < best ? key_ : best; }
 // a key whose index is NN_IDX_NONE (a dropped pixel: d2 = inf) or NN_KEY_NONE itself means "nothing found"
@@ -755,12 +778,27 @@ __device__ __forceinline__ unsigned long long org_scan(F fetch, int RS, int ou, 
   unsigned long long best = NN_KEY_NONE;
   const int wl = u_hi - u_lo, hl = v_hi - v_lo;
   const int b0 = (v_lo - ov) * RS + (u_lo - ou);
+#if FL_ICP_BATCH_CLAMP
+  // A batch is NBQ CONSECUTIVE positions from a clamped start (one address and immediate offsets instead of a clamp and
+  // an address per position).  A window narrower than NBQ reads up to NBQ - 1 = NN_OVERRUN positions past its right edge:
+  // the next pixels of the row, the start of the next row, or -- behind the last row -- the points the caller keeps there
+  // (copies of the last staged point / points at infinity behind the image).  All of them are reference points of this
+  // frame or points at infinity, and looking at more reference points never changes the nearest one.
+  static_assert(NBQ - 1 <= NN_OVERRUN, "the overrun guard behind the staged window / the image is NN_OVERRUN points");
+  const int wlc = max(wl - (NBQ - 1), 0);
+#endif
   for (int dv = 0; dv < maxh; ++dv) {
     const int rb = b0 + min(dv, hl) * RS;
     for (int du = 0; du < maxw; du += NBQ) {               // one batch at a time: the other waves of the SIMD cover the LDS latency
       float4 cur[NBQ];
+#if FL_ICP_BATCH_CLAMP
+      const int bb = rb + min(du, wlc);
+#pragma unroll
+      for (int e = 0; e < NBQ; ++e) cur[e] = fetch(bb + e);
+#else
 #pragma unroll
       for (int e = 0; e < NBQ; ++e) cur[e] = fetch(rb + min(du + e, wl));
+#endif
 #pragma unroll
       for (int e = 0; e < NBQ; ++e) NN_CONSIDER(cur[e])
     }
@@ -791,25 +829,47 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   const int ntiles = (n + TQ - 1) / TQ;
   // The phase is one memory round trip + one barrier per tile, so the next tile's (coalesced) loads are
   // issued before this tile is processed: the round trip overlaps the chain of the previous tile.
-  float pa[3] = {0.f, 0.f, 0.f}, pb[3] = {0.f, 0.f, 0.f}, pbnd = 0.f;
-  if (slot >= 0 && slot < n) {
-    const int i = slot;
-    { const F3 v3_ = ld3_u32(mod, i); pa[0] = v3_.x; pa[1] = v3_.y; pa[2] = v3_.z; }
-    { const F3 v3_ = ld3_u32(ref, i); pb[0] = v3_.x; pb[1] = v3_.y; pb[2] = v3_.z; }
-    if (Ropt) pbnd = ld_u32(bnd, i);
+  // (PD tiles ahead: with thousands of frames in flight the loads come from HBM, several thousand cycles under load,
+  // while the chain needs a tile every TQ * 8 cycles)
+  constexpr int PD = FL_ICP_PD;
+  float pa[PD][3], pb[PD][3], pbnd[PD];
+#pragma unroll
+  for (int k = 0; k < PD; ++k) { pa[k][0] = pa[k][1] = pa[k][2] = 0.f; pb[k][0] = pb[k][1] = pb[k][2] = 0.f; pbnd[k] = 0.f; }
+  if (slot >= 0) {
+#pragma unroll
+    for (int k = 0; k < PD; ++k) {
+      const int i = min(k * TQ + slot, n - 1);            // clamped: unused past the end
+      { const F3 v3_ = ld3_u32(mod, i); pa[k][0] = v3_.x; pa[k][1] = v3_.y; pa[k][2] = v3_.z; }
+      { const F3 v3_ = ld3_u32(ref, i); pb[k][0] = v3_.x; pb[k][1] = v3_.y; pb[k][2] = v3_.z; }
+      if (Ropt) pbnd[k] = ld_u32(bnd, i);
+    }
   }
+  const bool chain_wave = parity && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
+  if (FL_ICP_SPLIT && chain_wave) {
+    // the chain wave's own loop (see the A2 phase): one barrier per tile like the producers' below
+    for (int t = 0; t < ntiles; ++t) {
+      if (t > 0 && threadIdx.x == 0) acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
+      __syncthreads();
+    }
+  } else
   for (int t = 0; t < ntiles; ++t) {
     if (slot >= 0) {
       const int i = t * TQ + slot;
       float term = 0.0f;
-      float a[3] = {pa[0], pa[1], pa[2]};
-      const float b0 = pb[0], b1 = pb[1], b2 = pb[2];
-      const float bprev = pbnd;
+      float a[3] = {pa[0][0], pa[0][1], pa[0][2]};
+      const float b0 = pb[0][0], b1 = pb[0][1], b2 = pb[0][2];
+      const float bprev = pbnd[0];
       {
-        const int in = min(i + TQ, n - 1);                // clamped: unused past the end (this thread owns row i + TQ)
-        { const F3 v3_ = ld3_u32(mod, in); pa[0] = v3_.x; pa[1] = v3_.y; pa[2] = v3_.z; }
-        { const F3 v3_ = ld3_u32(ref, in); pb[0] = v3_.x; pb[1] = v3_.y; pb[2] = v3_.z; }
-        if (Ropt) pbnd = ld_u32(bnd, in);
+#pragma unroll
+        for (int k = 0; k + 1 < PD; ++k) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { pa[k][q] = pa[k + 1][q]; pb[k][q] = pb[k + 1][q]; }
+          pbnd[k] = pbnd[k + 1];
+        }
+        const int in = min(i + PD * TQ, n - 1);           // clamped: unused past the end (this thread owns row i + PD * TQ)
+        { const F3 v3_ = ld3_u32(mod, in); pa[PD - 1][0] = v3_.x; pa[PD - 1][1] = v3_.y; pa[PD - 1][2] = v3_.z; }
+        { const F3 v3_ = ld3_u32(ref, in); pb[PD - 1][0] = v3_.x; pb[PD - 1][1] = v3_.y; pb[PD - 1][2] = v3_.z; }
+        if (Ropt) pbnd[PD - 1] = ld_u32(bnd, in);
       }
       if (i < n) {
         if (Ropt) {
@@ -845,7 +905,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
       }
       if (parity) S.dtile[t & 1][slot] = term;            // non-inliers add an exact +0.0f
       if (DEFER && i < n) dterm[i] = term;
-    } else if (t > 0 && threadIdx.x == 0) {
+    } else if (!FL_ICP_SPLIT && t > 0 && threadIdx.x == 0) {
       acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
     }
     if (parity) __syncthreads();
@@ -975,9 +1035,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     float4 *stage = (float4 *)&S.prod[0][0][0] + wv * CAPW;
     const float4 *refimg = sref;
     const int last_s = n_model - 1;
+    float4 Rlast = make_float4(0.f, 0.f, 0.f, 0.f);       // the last point of the window being staged (lanes < NN_OVERRUN)
     struct Win {
       int u_lo, u_hi, v_lo, v_hi;        // this lane's window (crop pixels); a lane without one looks at (U0, V0)
-      int U0, V0, W, area, maxw, maxh;   // wave-uniform: union rectangle and the largest lane window
+      int U0, V0, W, H, area, maxw, maxh;   // wave-uniform: union rectangle and the largest lane window
       bool any, staged;                  // wave-uniform: some lane has a window; the union fits the LDS share
     };
     auto make_window = [&](const F3 &q, float b, bool queryable, Win &w) {
@@ -986,7 +1047,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const bool some = u_lo <= u_hi;
       const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
       w.any = U1 >= U0;
-      w.U0 = U0; w.V0 = 0; w.W = 1; w.area = 0; w.maxw = 0; w.maxh = 0; w.staged = false;
+      w.U0 = U0; w.V0 = 0; w.W = 1; w.H = 0; w.area = 0; w.maxw = 0; w.maxh = 0; w.staged = false;
       if (w.any) {
         const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
         w.maxw = wave_max_i(u_hi - u_lo + 1);
@@ -995,8 +1056,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
                                                              // reference point beyond their radius, which the gate drops
         w.V0 = V0;
         w.W = U1 - U0 + 1;
-        w.area = w.W * (V1 - V0 + 1);
-        w.staged = w.area <= CAPW;
+        w.H = V1 - V0 + 1;
+        w.area = w.W * w.H;
+        w.staged = w.area + NN_OVERRUN <= CAPW;
       }
       w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
     };
@@ -1016,6 +1078,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         idx += didx;
         if (col >= w.W) { col -= w.W; idx += og.cw - w.W; }
       }
+      // the overrun guard behind the window: NN_OVERRUN copies of its last point (lanes 0 .. NN_OVERRUN - 1 write them)
+      if (lane < NN_OVERRUN) Rlast = ld_u32(refimg, (int)__umul24((unsigned)(w.V0 + w.H - 1), (unsigned)og.cw) + w.U0 + w.W - 1);
     };
     auto write_stage = [&](const Win &w, const float4 (&R)[NST]) {
 #pragma unroll
@@ -1023,6 +1087,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         const int k = lane + 64 * j;
         if (k < w.area) stage[k] = R[j];
       }
+      if (lane < NN_OVERRUN) stage[w.area + lane] = Rlast;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1237,48 +1302,79 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     const int ntiles = (parity || index_pairs) ? (rows + TQ - 1) / TQ : 0;
     float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
     if (parity && iter > 1) {
-      // Two-deep register pipeline of the producers: a tile costs nn/mod loads (coalesced) and then the
-      // dependent gather ref[j]; tile t + 2's loads and tile t + 1's gather are in flight while tile t is
-      // written, so both round trips overlap the chains instead of adding up per tile.
-      int j1 = -1, j2 = -1;
-      float m1[3] = {0.f, 0.f, 0.f}, r1[3] = {0.f, 0.f, 0.f}, m2[3] = {0.f, 0.f, 0.f};
+      // Register pipeline of the producers: a tile costs nn/mod loads (coalesced) and then the dependent gather ref[j].
+      // With thousands of frames in flight both come from HBM (several thousand cycles under load) while the chain needs a
+      // tile every TQ * 8 cycles, so tile t + PD + 1's loads and the gathers of tiles t + 1 .. t + PD are in flight while
+      // tile t is written.
+      constexpr int PD = FL_ICP_PD;
+      int jq[PD + 1];
+      float mq[PD + 1][3], rq[PD][3];
+#pragma unroll
+      for (int k = 0; k <= PD; ++k) { jq[k] = -1; mq[k][0] = mq[k][1] = mq[k][2] = 0.f; }
+#pragma unroll
+      for (int k = 0; k < PD; ++k) rq[k][0] = rq[k][1] = rq[k][2] = 0.f;
       if (slot >= 0) {
-        const int i0 = slot, i1 = TQ + slot;
         // SPEC: nn[] holds the neighbour whatever its distance; the pair is kept if d <= dist_thr (:268; NaN = none found)
-        if (i0 < rows) { j1 = ld_u32(nn, i0); if (SPEC && !(ld_u32(nd, i0) <= thr)) j1 = -1; { const F3 v3_ = ld3_u32(mod, i0); m1[0] = v3_.x; m1[1] = v3_.y; m1[2] = v3_.z; } }
-        if (i1 < rows) { j2 = ld_u32(nn, i1); if (SPEC && !(ld_u32(nd, i1) <= thr)) j2 = -1; { const F3 v3_ = ld3_u32(mod, i1); m2[0] = v3_.x; m2[1] = v3_.y; m2[2] = v3_.z; } }
-        const int g = max(j1, 0);
-        { const F3 v3_ = ld3_u32(ref, g); r1[0] = v3_.x; r1[1] = v3_.y; r1[2] = v3_.z; }
+#pragma unroll
+        for (int k = 0; k <= PD; ++k) {
+          const int i0 = k * TQ + slot;
+          if (i0 < rows) {
+            jq[k] = ld_u32(nn, i0);
+            if (SPEC && !(ld_u32(nd, i0) <= thr)) jq[k] = -1;
+            const F3 v3_ = ld3_u32(mod, i0);
+            mq[k][0] = v3_.x; mq[k][1] = v3_.y; mq[k][2] = v3_.z;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < PD; ++k) {
+          const F3 v3_ = ld3_u32(ref, max(jq[k], 0));
+          rq[k][0] = v3_.x; rq[k][1] = v3_.y; rq[k][2] = v3_.z;
+        }
       }
+      const bool chain_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
+      if (FL_ICP_SPLIT && chain_wave) {
+        // the chain wave's own loop: one barrier per tile like the producers' below
+        for (int t = 0; t < ntiles; ++t) {
+          if (t > 0 && threadIdx.x < 15)
+            acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+          __syncthreads();
+        }
+      } else
       for (int t = 0; t < ntiles; ++t) {
         if (slot >= 0) {
-          const int i3 = min((t + 2) * TQ + slot, rows - 1);     // clamped: unused past the end
-          const bool in3 = (t + 2) * TQ + slot < rows;
+          const int i3 = min((t + PD + 1) * TQ + slot, rows - 1);     // clamped: unused past the end
+          const bool in3 = (t + PD + 1) * TQ + slot < rows;
           int j3 = ld_u32(nn, i3);
           const float d3 = SPEC ? ld_u32(nd, i3) : 0.0f;
           const F3 m3v = ld3_u32(mod, i3);
-          const float m3[3] = {m3v.x, m3v.y, m3v.z};
           j3 = in3 && (!SPEC || d3 <= thr) ? j3 : -1;
-          const int g = max(j2, 0);
-          const F3 r2v = ld3_u32(ref, g);
-          const float r2[3] = {r2v.x, r2v.y, r2v.z};
-          const bool have = j1 >= 0;                     // dropped pairs contribute an exact +0.0f: (+0) * (+0)
+          const F3 rNv = ld3_u32(ref, max(jq[PD], 0));   // the gather of tile t + PD
+          const bool have = jq[0] >= 0;                  // dropped pairs contribute an exact +0.0f: (+0) * (+0)
           if (SPEC && have) ++kept;
           float (*tile)[SH::TS] = S.prod[t & 1];
           float mm[3], rr[3];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) { mm[q] = have ? m1[q] : 0.0f; rr[q] = have ? r1[q] : 0.0f; }
+          for (int q = 0; q < 3; ++q) { mm[q] = have ? mq[0][q] : 0.0f; rr[q] = have ? rq[0][q] : 0.0f; }
 #pragma unroll
           for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = mm[a] * rr[b];   // (*it_s) * (*it_ref).t()
 #pragma unroll
           for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = mm[q]; tile[12 + q][slot] = rr[q]; }
-          j1 = j2;
 #pragma unroll
-          for (int q = 0; q < 3; ++q) { m1[q] = m2[q]; r1[q] = r2[q]; m2[q] = m3[q]; }
-          j2 = j3;
-        } else if (t > 0 && threadIdx.x < 15) {
+          for (int k = 0; k < PD; ++k) {
+            jq[k] = jq[k + 1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) mq[k][q] = mq[k + 1][q];
+          }
+#pragma unroll
+          for (int k = 0; k + 1 < PD; ++k)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) rq[k][q] = rq[k + 1][q];
+          rq[PD - 1][0] = rNv.x; rq[PD - 1][1] = rNv.y; rq[PD - 1][2] = rNv.z;
+          jq[PD] = j3;
+          mq[PD][0] = m3v.x; mq[PD][1] = m3v.y; mq[PD][2] = m3v.z;
+        } else if (!FL_ICP_SPLIT && t > 0 && threadIdx.x < 15) {
           acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
         }
         __syncthreads();
@@ -1544,8 +1640,7 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
     for (int i = 0; i < NW; ++i) { const int c = slot[i]; before += i < wv ? c : 0; total += c; }
     // the reference cloud as an image (organised search): the point and its index, or a point at infinity
     if (p < np)
-      refimg[p] = keep ? make_float4(A[0], A[1], A[2], __int_as_float(kept_before + before + in_wave))
-                       : make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(NN_IDX_NONE));
+      refimg[p] = keep ? nn_point(A[0], A[1], A[2], kept_before + before + in_wave) : nn_point(INFINITY, INFINITY, INFINITY, NN_IDX_NONE);
     if (keep) {
       const int k = kept_before + before + in_wave;
       ref[3 * k] = A[0]; ref[3 * k + 1] = A[1]; ref[3 * k + 2] = A[2];
@@ -1558,13 +1653,14 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
     }
     kept_before += total;
   }
+  if (threadIdx.x < NN_OVERRUN) refimg[np + threadIdx.x] = nn_point(INFINITY, INFINITY, INFINITY, NN_IDX_NONE);   // overrun guard (org_scan)
   __syncthreads();                                         // the clouds are complete for every thread
   return kept_before;
 }
 
 // The model indices in 8x8-pixel tile order (tile rows alternately left-to-right and right-to-left, so consecutive tiles
 // are neighbours): the 64 queries a wave takes per step then project into a compact window of the reference image.
-// Index k of crop pixel p is refimg[p].w (the paired compaction keeps the same pixels of both clouds).
+// Index k of crop pixel p is nn_point_index(refimg[p]) (the paired compaction keeps the same pixels of both clouds).
 template <class SH>
 __device__ __forceinline__ void build_tile_order(SH &S, const float4 *refimg, int cw, int ch, int n, int *perm)
 {
@@ -1585,7 +1681,7 @@ __device__ __forceinline__ void build_tile_order(SH &S, const float4 *refimg, in
     if (ty & 1) tx = ntx - 1 - tx;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     int k = NN_IDX_NONE;
-    if (x < cw && y < ch) k = __float_as_int(refimg[y * cw + x].w);
+    if (x < cw && y < ch) k = nn_point_index(refimg[y * cw + x]);
     has = (unsigned)k < (unsigned)NN_IDX_NONE;
     return k;
   };
