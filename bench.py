@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--templates", type=int, default=2000)
     ap.add_argument("--levels", type=int, default=0, help="pyramid levels (default: 2 for c2, 3 for c3)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per step per GPU (default 2048 for c2 = two rounds of 4 ICP workgroups on each of the 256 CUs; 256 for c3)")
+                    help="frames per step per GPU (default 2560 for c2 = two rounds of 5 ICP workgroups on each of the 256 CUs; 256 for c3)")
     ap.add_argument("--icp-iters", type=int, default=20)
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=16)
@@ -74,7 +74,7 @@ def parse():
     if a.levels == 0:
         a.levels = 3 if a.config == "c3" else 2
     if a.batch == 0:
-        a.batch = 256 if a.config == "c3" else 2048
+        a.batch = 256 if a.config == "c3" else 2560
     return a
 
 
@@ -466,7 +466,7 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
     BASELINE configs[1] and the data-independent eager front-end -- each a short run of its own."""
     out = {}
     sweep = []
-    for b in (1, 8, 64, 256, 1024, 2048):
+    for b in (1, 8, 64, 256, 1024, 2048, 2560):
         if b > args.batch:
             continue
         el1 = run.timed(1, 1, n=b)
@@ -478,7 +478,7 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
     out["batch_sweep"] = sweep
     out["batch1_latency_ms"] = sweep[0]["ms_per_step"] if sweep and sweep[0]["batch"] == 1 else None
     out["batch_sweep_note"] = ("one Recognition() per camera frame is the reference's call pattern; batches that leave CUs idle run one "
-                               "1024-thread ICP workgroup per frame, full batches 256-thread ones (5 per CU)")
+                               "1024-thread ICP workgroup per frame, full batches 256-thread ones (4 or 5 per CU, whichever finishes the batch sooner)")
     if bank.n_pyramids > 360:
         r2 = Runner(ctx, args, bank.subset(0, 360), bgrs, depths, w, h, K)
         el = r2.timed(4, 1)

@@ -53,9 +53,10 @@
 #define TSTAMP(k) do { } while (0)
 #endif
 #ifndef FL_ICP_WPE
-#define FL_ICP_WPE 4               // waves per SIMD the 256-thread recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96).  Measured
-                                  // on one box, ICP us per frame: 5 @ 1280 frames 11.65, 4 @ 1024 10.8, 4 @ 2048 10.4: the 96-VGPR build
-                                  // spills in the search loop
+#define FL_ICP_WPE 4               // waves per SIMD the default 256-thread recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96; a
+                                  // second instance for 5 is always built, see k_icp_pipeline).  ICP us per frame, one box: mid-round
+                                  // 5 @ 1280 frames 11.65, 4 @ 2048 10.4 (the 96-VGPR build spilled in the search loop); after the scan
+                                  // batches lost 10 instructions and a few registers: 5 @ 2560 9.76, 4 @ 2048 10.15
 #endif
 #ifndef FL_ICP_FAST_F32
 #define FL_ICP_FAST_F32 1          // FL_ICP_FAST keeps its per-thread partial sums (~60 terms) in float32, like the point-to-plane mode;
@@ -1739,8 +1740,11 @@ __global__ __launch_bounds__(BS) void k_icp_clouds(IcpArgs a)
   icp_run<MODE, false>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp, none);
 }
 
-template <int MODE, int BS>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(ICP_WPE(MODE, BS), ICP_WPE(MODE, BS) > 4 ? ICP_WPE(MODE, BS) : 4)))
+// WPE: waves per SIMD this instance is compiled for.  The 256-thread parity kernel exists twice, for 4 (128 VGPRs) and for 5
+// (96 VGPRs, a few more spills) workgroups per CU: 5 per CU finish a full round of 5 x #CUs frames 4 % faster per frame,
+// 4 per CU win when the batch is not a multiple of that (icp_small_wpe).
+template <int MODE, int BS, int WPE = ICP_WPE(MODE, BS)>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(WPE, WPE > 4 ? WPE : 4)))
 void k_icp_pipeline(IcpArgs a)
 {
   extern __shared__ __align__(16) uint8_t icp_smem[];
@@ -1939,7 +1943,8 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
   return FL_OK;
 }
 
-static_assert(sizeof(IcpSharedT<ICP_BS_SMALL>) + 16 <= 160 * 1024 / FL_ICP_WPE, "IcpSharedT<256> must leave room for FL_ICP_WPE workgroups per CU");
+#define ICP_WPE_MAX 5
+static_assert(sizeof(IcpSharedT<ICP_BS_SMALL>) + 16 <= 160 * 1024 / ICP_WPE_MAX, "IcpSharedT<256> must leave room for 5 workgroups per CU");
 static_assert(sizeof(IcpSharedT<ICP_BS_WIDE>) + 16 <= 160 * 1024, "IcpSharedT<1024> must fit the CU's LDS");
 template <int BS, typename K>
 static int icp_launch_one(fl_context *ctx, K kern, int n_jobs, const IcpArgs &a)
@@ -1964,10 +1969,25 @@ static bool icp_wide(fl_context *ctx, int n_jobs)
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   return n_jobs <= 2 * cus;
 }
+// Workgroups per CU of the 256-thread parity kernel: whichever of 4 and 5 needs less time for n_jobs by the measured cost of
+// a full round (5 per CU: 1.20 x the time of 4 per CU for 1.25 x the frames; 360 templates, one box: 2560 frames 24.97 ms
+// against 2048 frames 20.78 ms).  FL_ICP_OCC=4/5 forces one (dev knob).
+static int icp_small_wpe(fl_context *ctx, int n_jobs)
+{
+  const char *env = getenv("FL_ICP_OCC");
+  if (env && (env[0] == '4' || env[0] == '5')) return env[0] - '0';
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int r4 = (n_jobs + 4 * cus - 1) / (4 * cus), r5 = (n_jobs + 5 * cus - 1) / (5 * cus);
+  return 1.20 * r5 < 1.0 * r4 ? 5 : 4;
+}
 template <int MODE>
 static int icp_launch_mode(fl_context *ctx, int n_jobs, const IcpArgs &a)
 {
   const bool wide = icp_wide(ctx, n_jobs);
+  if (MODE == FL_ICP_PARITY && a.job.kind != 2 && !wide && icp_small_wpe(ctx, n_jobs) == 5)
+    return icp_launch_one<ICP_BS_SMALL>(ctx, k_icp_pipeline<MODE, ICP_BS_SMALL, 5>, n_jobs, a);
   if (a.job.kind == 2)
     return wide ? icp_launch_one<ICP_BS_WIDE>(ctx, k_icp_clouds<MODE, ICP_BS_WIDE>, n_jobs, a)
                 : icp_launch_one<ICP_BS_SMALL>(ctx, k_icp_clouds<MODE, ICP_BS_SMALL>, n_jobs, a);

@@ -48,11 +48,14 @@ def test_depth_to_3d_bit_exact(ctx, oracle, w, h, K):
     assert np.array_equal(_bits(np.nan_to_num(got)), _bits(np.nan_to_num(exp)))
 
 
-@pytest.fixture(params=["1024", "256"])
+@pytest.fixture(params=["1024", "256", "256x5"])
 def width(request, monkeypatch):
-    """Both builds of the ICP kernels: the library picks the 1024-thread workgroup for batches of up to two jobs per CU (with the
-    search running ahead of the dist_mean chain) and the 256-thread one beyond; FL_ICP_WIDE forces either for any batch."""
+    """Every build of the ICP kernels: the library picks the 1024-thread workgroup for batches of up to two jobs per CU (with the
+    search running ahead of the dist_mean chain) and a 256-thread one beyond, compiled for 4 or for 5 workgroups per CU (whichever
+    finishes the batch sooner); FL_ICP_WIDE and FL_ICP_OCC force any of them for any batch."""
     monkeypatch.setenv("FL_ICP_WIDE", "1" if request.param == "1024" else "0")
+    if request.param == "256x5":
+        monkeypatch.setenv("FL_ICP_OCC", "5")
     return request.param
 
 

@@ -9,7 +9,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B=${B:-2048}
+B=${B:-2560}
 T=${T:-2000}
 CMD="python3 bench.py --steps 5 --warmup 2 --batch $B --templates $T --no-cpu-baseline --no-extras"
 out=gpurun_out/prof_final
