@@ -18,9 +18,10 @@
 //   * FL_ICP_FAST: per-thread partials + fixed-shape fp64 tree, rounded once to float32.
 //   * FL_ICP_POINT_TO_PLANE (no reference counterpart): NN pairs from the first
 //     iteration on, 27 fp64 sums of the linearised point-to-plane system, 6x6 Cholesky + Rodrigues.
-// The workgroup is 256 threads at full batches (5 workgroups per CU) and 1024 threads when the batch
-// would leave CUs idle anyway (a camera-rate caller: 1-8 frames): the search and the chain producers get
-// 4x the lanes and a frame's latency drops to about what its sequential chains cost.
+// The workgroup is 256 threads at full batches (built for 4 and for 5 workgroups per CU: icp_small_wpe picks) and 1024 threads
+// when the batch would leave CUs idle anyway (up to two frames per CU; a camera-rate caller: 1-8 frames): the search and the
+// chain producers get 4x the lanes, the next iteration's search runs underneath the dist_mean chain ("Search ahead of the
+// distance chain" in icp_run), and a frame's latency drops to about what its two sequential chains cost.
 //
 // Nearest neighbours: the reference's FLANN kd-tree (exact 1-NN, eps 0) is replaced by a uniform
 // x/y cell grid over the static reference cloud built once per frame; a query only visits the
