@@ -313,6 +313,10 @@ def main():
         print("icp organised search per frame: steps %.0f, positions per step %.1f (iterations 1-3: %.0f%% of all), fallback steps %.1f%%, "
               "staged points per step %.0f" % (st[0], st[1] / max(st[0], 1), 100 * st[4] / max(st[1], 1), 100 * st[2] / max(st[0], 1),
                                                 st[3] / max(st[0], 1)), file=sys.stderr)
+    if os.environ.get("FL_BENCH_NPTS") and args.config != "c3":            # dev aid: how uneven are the jobs of one ICP launch?
+        npt = np.array([int(r.det.n_points) for r in res if r.found])
+        print("icp n_points: found %d of %d, min / median / mean / max %d / %d / %d / %d, p5 / p95 %d / %d" %
+              (len(npt), len(res), npt.min(), np.median(npt), npt.mean(), npt.max(), *np.percentile(npt, [5, 95])), file=sys.stderr)
     frames = B * args.steps * world
     value = frames / el
     if args.config == "c3":
