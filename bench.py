@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 L2_PEAK_GBS = 34500.0        # same guide: aggregate L2 bandwidth over the 8 XCDs
 FORCE_ALL_ITERS = -3.0e38    # dist_diff_thr that never stops the loop: exactly icp_it_thr iterations
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 def parse():
@@ -55,6 +55,13 @@ def parse():
     ap.add_argument("--scenes", type=int, default=16)
     ap.add_argument("--shard", choices=["frames", "templates"], default="frames")
     ap.add_argument("--topk", type=int, default=64, help="records per rank in the template-sharded all-gather")
+    ap.add_argument("--match-threshold", type=float, default=75.0,
+                    help="--shard templates: Detector::match threshold (the overflow rehearsal of the tests lowers it)")
+    ap.add_argument("--max-candidates", type=int, default=4096, help="initial per-frame capacity of the candidate / match buffers")
+    ap.add_argument("--sharded-host-merge", action="store_true",
+                    help="--shard templates: the round-2 path (records and poses staged through the host, numpy merge) instead of the device one")
+    ap.add_argument("--compare-host-merge", action="store_true",
+                    help="--shard templates: also time the host-merge path and report it beside the device path's figure")
     ap.add_argument("--verify-sharded", action="store_true",
                     help="--shard templates: rank 0 also runs one detector over the whole bank and checks every frame's result bit for bit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,6 +77,10 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (implies a non-RCCL backend)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins the process group (gloo), one all-reduce, rank 0 prints the line's "
+                         "launch fields -- the CPU test of the --gpus N self-launch")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launch (0 = pick a free one)")
     a = ap.parse_args()
     if a.levels == 0:
         a.levels = 3 if a.config == "c3" else 2
@@ -88,10 +99,12 @@ def t_pyramid(levels):
     return [5, 8, 4][:levels] if levels == 3 else [5, 8][:levels]
 
 
-def build_bank(ctx, args, n_templates, w, h, K):
+def build_bank(ctx, args, n_templates, w, h, K, spread_trained=False):
     """Scenes + template bank.  Templates = rendered views of the object near each scene pose,
     trained with the product's own addTemplate (fl_extract_template_pyramid; they win the detection and feed ICP with
-    real clouds), padded with random templates (the scan's work is data-independent).  Same bank on every rank."""
+    real clouds), padded with random templates (the scan's work is data-independent).  Same bank on every rank.
+    spread_trained: the trained views are dealt evenly over the bank instead of leading it, so that a template-sharded
+    run has winners (and ICP work) on every rank."""
     from fealess_amd import synth
     from fealess_amd.bank import TemplateBank
     levels = args.levels
@@ -106,8 +119,8 @@ def build_bank(ctx, args, n_templates, w, h, K):
         return ex[0], synth.pose13(Rv, tv), (d_obj.astype(np.uint32) * 10).clip(0, 65535).astype(np.uint16)
 
     rng = np.random.default_rng(1234)
-    bank = TemplateBank("obj", levels, 2)
     scenes = []
+    trained = []
     for s in range(args.scenes):
         R, t = synth.object_pose(tx=float(rng.uniform(-60, 60)), ty=float(rng.uniform(-40, 40)),
                                  tz=float(rng.uniform(620, 700)), yaw=float(rng.uniform(-0.4, 0.4)),
@@ -118,10 +131,17 @@ def build_bank(ctx, args, n_templates, w, h, K):
             dR = synth.rot_z(np.deg2rad(rng.uniform(-2, 2))) @ synth.rot_x(np.deg2rad(rng.uniform(-2, 2)))
             tt = t + np.array([rng.uniform(-20, 20), rng.uniform(-15, 15), rng.uniform(-8, 8)])
             out = trained_template(dR @ R, tt, seed=1000 + 10 * s + v)
-            if out is not None and bank.n_pyramids < n_templates:
-                bank.add_pyramid(*out)
-    while bank.n_pyramids < n_templates:       # no depth render: they never win against the trained views
-        bank.add_pyramid(synth.random_pyramid(rng, levels, 2, w, h), None, None)
+            if out is not None and len(trained) < n_templates:
+                trained.append(out)
+    # where the trained views sit in the bank: leading it (default), or every (n / trained)-th pyramid
+    nt = len(trained)
+    at = {((j * n_templates) // nt if spread_trained else j): j for j in range(nt)}
+    bank = TemplateBank("obj", levels, 2)
+    for i in range(n_templates):
+        if i in at:
+            bank.add_pyramid(*trained[at[i]])
+        else:                                     # no depth render: they never win against the trained views
+            bank.add_pyramid(synth.random_pyramid(rng, levels, 2, w, h), None, None)
     return bank, scenes
 
 
@@ -153,8 +173,13 @@ def cpu_baseline(args, bank, scenes, K):
             O.recognition(bgr, depth, K, T, bank, 75.0, args.icp_iters, -1.0, FORCE_ALL_ITERS, accum64=False, use_kdtree=True)
 
     n, t0 = 0, time.perf_counter()
+    lm_ms = icp_ms = 0.0
     while True:
         one(*scenes[n % len(scenes)])
+        if args.config != "c3":
+            a, b = O.last_stage_ms()
+            lm_ms += a
+            icp_ms += b
         n += 1
         el = time.perf_counter() - t0
         if el >= args.cpu_seconds or n >= 64:
@@ -163,11 +188,18 @@ def cpu_baseline(args, bank, scenes, K):
     single = dict(value=n / el, unit="frames/s", cores=1, kind="port",
                   sample=f"{n} frames of the same workload ({bank.n_pyramids} templates, {what}), "
                          f"oracle/liboracle.so single-threaded (the reference is single-threaded), {el:.1f} s")
+    if args.config != "c3":
+        # the reference's own timer points: "Time of linemod" = Detector::match (CadReco/obj_reco_lmicp.cpp:88,124-125),
+        # "Time of ICP" = the rest of Recognition() up to the pose (:126,201-202)
+        single["linemod_ms"] = round(lm_ms / n, 3)
+        single["icp_ms"] = round(icp_ms / n, 3)
+        single["stage_note"] = ("per frame, at the reference's timer points (obj_reco_lmicp.cpp:125 'Time of linemod', :202 'Time of ICP'); "
+                                "the GPU's per-frame figures for the same two stages are gpu_stage_ms_per_frame")
     # SURVEY 8(d) also asks for the restatement over all host cores: frames are independent, one per thread
     # (ctypes releases the GIL during the call; the oracle keeps no shared mutable state)
     import concurrent.futures as cf
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))                                        # the CPU share of a one-GPU box
+    cores = max(1, cores)                                                 # every host core this process may run on
     per_thread = max(1, int(round(n / el * args.cpu_seconds / 2)))       # about cpu_seconds / 2 of work per thread
 
     def work(k):
@@ -180,7 +212,8 @@ def cpu_baseline(args, bank, scenes, K):
         done = sum(ex.map(work, range(cores)))
     el2 = time.perf_counter() - t1
     single["all_cores"] = dict(value=done / el2, unit="frames/s", cores=cores,
-                               sample=f"{done} frames, one frame per thread at a time, {el2:.1f} s")
+                               sample=f"{done} frames, one frame per thread at a time on all {cores} host cores of this box "
+                                      f"(os.sched_getaffinity), {el2:.1f} s")
     single["note"] = ("a scalar port: roughly half of its time is front-end filtering that OpenCV's SIMD kernels do an order of "
                       "magnitude faster, so value / cpu_baseline.value says little about the reference itself")
     return single
@@ -254,15 +287,69 @@ class Runner:
         self.torch.cuda.synchronize()
 
     def close(self):
-        self.det.close()
+        if self.det is not None:
+            self.det.close()
+            self.det = None
+            self.d_bgr = self.d_depth = None
+            self.torch.cuda.empty_cache()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE): this parent -- which never imports torch and never
+    touches the GPU -- starts the N ranks as a CHILD process (torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1), relays their output and exits with the child's code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if port == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    for line in proc.stdout:                               # rank 0's JSON line (and nothing else) arrives on stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def launch_check(args, world, rank):
+    """--launch-check: the distributed plumbing of the line without a GPU (gloo)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        assert int(t.item()) == world
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "gpus_flag": args.gpus,
+                          "collectives": {"backend": "gloo" if world > 1 else None, "ranks": world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...), or "
+                         f"start `python bench.py --gpus {args.gpus}` plainly and it launches the ranks itself")
+    if args.launch_check:
+        return launch_check(args, world, rank)
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -280,7 +367,7 @@ def main():
     T = t_pyramid(args.levels)
     if args.shard == "templates":
         from fealess_amd import bench_sharded
-        out = bench_sharded.run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames)
+        out = bench_sharded.run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames, cpu_baseline=cpu_baseline)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if dist is not None:
@@ -323,12 +410,27 @@ def main():
         out = line_c3(args, run, res, times, value, el, world, bank, T)
     else:
         out = line_c2(args, run, res, times, value, el, world, bank, T, bgrs, depths, sync_all)
+    dev_ids = [local_rank]
+    if dist is not None:
+        ids = [None] * world
+        dist.all_gather_object(ids, int(torch.cuda.current_device()))
+        dev_ids = ids
+    out["collectives"] = {"backend": (dist.get_backend() if dist is not None else None), "ranks": world, "device_ids": dev_ids,
+                          "data_path": "none (frame-sharded: disjoint frames per rank, whole bank replicated)",
+                          "timing": "barrier + all_reduce(MAX) of the ranks' elapsed time" if dist is not None else "single rank"}
     if rank == 0:
         if not args.no_extras and world == 1 and args.config == "c2":
             out.update(extras(args, ctx, run, bank, bgrs, depths, w, h, K))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, bank, scenes, K)
-            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline"] = cb = cpu_baseline(args, bank, scenes, K)
+            out["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
+            if "linemod_ms" in cb and "stage_ms_last_step" in out:
+                st = out["stage_ms_last_step"]
+                g_lm = (st["total_ms"] - st["icp_ms"]) / B
+                g_icp = st["icp_ms"] / B
+                cb["gpu_stage_ms_per_frame"] = dict(linemod_ms=round(g_lm, 6), icp_ms=round(g_icp, 6),
+                                                    note="device time of the last step / frames: front-end + linear memories + scan + refine + sort, and the ICP launch")
+                cb["stage_speedup"] = dict(linemod=round(cb["linemod_ms"] / g_lm, 1), icp=round(cb["icp_ms"] / g_icp, 1))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -500,6 +602,66 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
                                      note="finer pyramid levels quantised and spread in full before the scan (the reference's order): the "
                                           "data-independent figure; same results")
         r3.close()
+    if args.icp_mode == "parity":
+        # FL_ICP_FAST (parallel sums instead of the reference's float32 chains): not bit-identical to the reference's arithmetic,
+        # within the north_star's 1e-4 of it (tests/test_gpu_icp.py::test_icp_fast_mode_vs_the_f32_oracle_and_fp64)
+        af = argparse.Namespace(**vars(args))
+        af.icp_mode = "fast"
+        r4 = Runner(ctx, af, bank, bgrs, depths, w, h, K)
+        el = r4.timed(4, 1)
+        _, t = r4.collect()
+        el1 = r4.timed(20, 2, n=1)
+        _, t1 = r4.collect(1)
+        out["icp_fast"] = dict(value=round(args.batch * 4 / el, 1), unit="frames/s", ms_per_step=round(el / 4 * 1e3, 4),
+                               icp_ms=round(t["icp_ms"], 4), batch1_latency_ms=round(el1 / 20 * 1e3, 4), batch1_icp_ms=round(t1["icp_ms"], 4),
+                               note="--icp-mode fast: float32 per-thread partial sums + fp64 tree instead of the reference-order float32 chains; "
+                                    "pose within 1e-4 (R) of the float32 oracle, not bit-identical; never the headline value")
+        r4.close()
+    run.close()                                           # the default workload's 16 GB of workspaces make room for the other configs
+    out.update(other_configs(args, ctx))
+    return out
+
+
+def other_configs(args, ctx):
+    """BASELINE configs[0] and configs[2] on this GPU, each a short run of its own, so that one driver run records every
+    single-GPU configuration (configs[1] is `c2_360_templates`, the headline is configs[1]'s shape at 2000 templates)."""
+    out = {}
+    # configs[2]: 1280x720, 2000 templates, 3 levels T = {5, 8, 4}, Detector::match only (= `bench.py --config c3`)
+    a3 = argparse.Namespace(**vars(args))
+    a3.config, a3.levels, a3.batch, a3.templates, a3.icp_mode = "c3", 3, 256, 2000, "parity"
+    w3, h3, K3 = geometry(a3)
+    bank3, scenes3 = build_bank(ctx, a3, a3.templates, w3, h3, K3)
+    b3, d3 = build_frames(scenes3, a3.batch, 0, w3, h3)
+    r3 = Runner(ctx, a3, bank3, b3, d3, w3, h3, K3)
+    steps = 8
+    el = r3.timed(steps, 2)
+    res3, t3 = r3.collect()
+    line = line_c3(a3, r3, res3, t3, a3.batch * steps / el, el, 1, bank3, t_pyramid(3))
+    out["c3_1280x720"] = dict(value=line["value"], unit="frames/s", ms_per_step=round(el / steps * 1e3, 4), frames_per_step=a3.batch,
+                              stage_ms=line["stage_ms_last_step"], scan_l2_frac=line["roofline"]["l2_frac"],
+                              scan_achieved_GBs=line["roofline"]["achieved"], matches_first_frames=line["matches_first_frames"],
+                              workload=line["config"]["workload"])
+    r3.close()
+    del r3, b3, d3
+    # configs[0]: one 640x480 frame, 16 templates, 1 pyramid level (T = {5}: the scan runs at level 0), match + ICP
+    a1 = argparse.Namespace(**vars(args))
+    a1.config, a1.levels, a1.batch, a1.templates, a1.icp_mode = "c2", 1, 256, 16, "parity"
+    w1, h1, K1 = geometry(a1)
+    bank1, scenes1 = build_bank(ctx, a1, a1.templates, w1, h1, K1)
+    b1, d1 = build_frames(scenes1, a1.batch, 0, w1, h1)
+    r1 = Runner(ctx, a1, bank1, b1, d1, w1, h1, K1)
+    el1 = r1.timed(20, 2, n=1)
+    res1, t1 = r1.collect(1)
+    elb = r1.timed(4, 1)
+    resb, tb = r1.collect()
+    out["c1_16_templates_1_level"] = dict(
+        batch1_latency_ms=round(el1 / 20 * 1e3, 4), batch1_stage_ms={k: round(v, 4) for k, v in t1.items() if k.endswith("_ms")},
+        value=round(a1.batch * 4 / elb, 1), unit="frames/s", frames_per_step=a1.batch, ms_per_step=round(elb / 4 * 1e3, 4),
+        stage_ms={k: round(v, 4) for k, v in tb.items() if k.endswith("_ms")},
+        detections=f"{sum(int(r.found) for r in resb)}/{a1.batch}",
+        workload=f"BASELINE configs[0] on the GPU: 640x480, {bank1.n_pyramids} templates, 1 pyramid level T=[5], Recognition with "
+                 f"{a1.icp_iters} ICP iterations forced; one frame per call (batch1_*) and {a1.batch} frames per step")
+    r1.close()
     return out
 
 

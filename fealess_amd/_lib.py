@@ -63,6 +63,8 @@ class StageTimes(C.Structure):
                 ("lazy_frontend_ms", C.c_float), ("reserved0", C.c_float)]
 
 
+FL_TOPK_OVERFLOW = -2      # fl_export_topk_batch: template id of record 0 of a frame whose candidate buffers overflowed
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -81,6 +83,7 @@ SIGNATURES = {
     "fl_detector_add_class": (_I, [_P, C.c_char_p, _I, _P, _P, _I, _P]),
     "fl_detector_set_model_depths": (_I, [_P, _I, _I, _I, _P, _I, _I, _I]),
     "fl_detector_finalize": (_I, [_P, _I, _I, _I, _I]),
+    "fl_detector_grow_candidates": (_I, [_P, _I, C.POINTER(_I)]),
     "fl_detector_set_class_filter": (_I, [_P, C.POINTER(C.c_char_p), _I]),
     "fl_detector_num_templates": (_I, [_P]),
     "fl_detector_num_classes": (_I, [_P]),
@@ -120,6 +123,8 @@ SIGNATURES = {
     "fl_export_topk_batch": (_I, [_P, _I, _I, _I, _P]),
     "fl_merge_topk_batch": (_I, [_P, _I, _I, _I, _P, _I, C.POINTER(_I)]),
     "fl_refine_matches": (_I, [_P, _I, C.POINTER(C.c_int32), _P, C.POINTER(Intrinsics), C.POINTER(RecognitionParams), _P]),
+    "fl_select_best_batch": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "fl_refine_selected": (_I, [_P, _I, C.POINTER(Intrinsics), C.POINTER(RecognitionParams), _P, C.c_size_t, _P]),
     "fl_last_stage_times": (_I, [_P, C.POINTER(StageTimes)]),
     "fl_frame_counters": (_I, [_P, _I, C.POINTER(C.c_int32)]),
 }

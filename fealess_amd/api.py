@@ -217,10 +217,20 @@ class Detector:
     def finalize(self, w0, h0, max_batch=1, max_candidates=0):
         # model depth renders first (class order = sorted class ids)
         for ci, b in enumerate(self.banks):
-            if b.model_depths:             # the leading pyramids' renders (bank.py); the rest have none and cannot be refined
-                d = np.ascontiguousarray(np.stack(b.model_depths), np.uint16)
-                self.ctx.check(self.lib.fl_detector_set_model_depths(self.h, ci, 0, len(b.model_depths), _ptr(d), d.shape[2],
-                                                                     d.shape[1], L.FL_MEM_HOST))
+            # render i belongs to pyramid i (bank.py); pyramids without one (None / behind the list's end) keep an empty
+            # render and cannot be refined.  One upload per run of consecutive renders.
+            i, n = 0, len(b.model_depths)
+            while i < n:
+                if b.model_depths[i] is None:
+                    i += 1
+                    continue
+                j = i
+                while j < n and b.model_depths[j] is not None:
+                    j += 1
+                d = np.ascontiguousarray(np.stack(b.model_depths[i:j]), np.uint16)
+                self.ctx.check(self.lib.fl_detector_set_model_depths(self.h, ci, i, j - i, _ptr(d), d.shape[2], d.shape[1],
+                                                                     L.FL_MEM_HOST))
+                i = j
         self.ctx.check(self.lib.fl_detector_finalize(self.h, w0, h0, max_batch, max_candidates))
         self.w0, self.h0, self.max_batch = w0, h0, max_batch
 
@@ -382,6 +392,24 @@ class Detector:
         res = (L.RecognitionResult * n)()
         self.ctx.check(self.lib.fl_refine_matches(self.h, n, fr, _ptr(m), C.byref(k), C.byref(params), res))
         return res
+
+    def grow_candidates(self, n_frames):
+        """fl_detector_grow_candidates: after a queued batch reported an overflow; returns the capacity afterwards."""
+        cap = C.c_int(0)
+        self.ctx.check(self.lib.fl_detector_grow_candidates(self.h, n_frames, C.byref(cap)))
+        return cap.value
+
+    def select_best_batch(self, dev_gathered, n_ranks, n_frames, k, tid_first, tid_count, dev_best):
+        """fl_select_best_batch: per frame matches[0] of the global sort over the ranks' all-gathered records (device
+        pointers in and out); this rank's refinement jobs stay in the detector."""
+        self.ctx.check(self.lib.fl_select_best_batch(self.h, C.c_void_p(dev_gathered), n_ranks, n_frames, k, tid_first, tid_count,
+                                                     C.c_void_p(dev_best)))
+
+    def refine_selected(self, n_frames, K, params, dev_rows, depth_base=None, depth_stride=0):
+        """fl_refine_selected: ICP of the selected jobs, {found, 4x4 pose} rows (float32 [n_frames, 17]) written to dev_rows."""
+        k = L.Intrinsics(self.w0, self.h0, *K)
+        self.ctx.check(self.lib.fl_refine_selected(self.h, n_frames, C.byref(k), C.byref(params),
+                                                   C.c_void_p(depth_base) if depth_base else None, depth_stride, C.c_void_p(dev_rows)))
 
     def close(self):
         if self.h:

@@ -24,8 +24,8 @@ class TemplateBank:
         self._features = []       # list of (n,3) int arrays
         self._nfeat = 0
         self.poses = []           # list of 13 floats
-        self.model_depths = []    # list of (h,w) uint16 arrays in 0.1 mm: the depth renders of the FIRST len(model_depths)
-                                  # pyramids (pyramids without one -- random throughput templates -- must come last)
+        self.model_depths = []    # model_depths[i]: (h,w) uint16 depth render (0.1 mm) of pyramid i, or None; the list may be
+                                  # shorter than the bank (the pyramids behind its end have no render and cannot be refined)
         self._frozen = None
 
     @property
@@ -36,6 +36,10 @@ class TemplateBank:
         """templates: list (levels*modalities, order [l*M+m]) of dicts with width, height, offset_x,
         offset_y, pyramid_level, features (n,3) int array."""
         assert len(templates) == self.levels * self.modalities
+        if model_depth is not None:
+            # render i belongs to pyramid i: pyramids added without one in between get an explicit None, so that a later
+            # render can never be taken for an earlier pyramid's
+            self.model_depths.extend([None] * (self.n_pyramids - len(self.model_depths)))
         for t in templates:
             f = np.asarray(t["features"], dtype=np.int32).reshape(-1, 3)
             self._templates.append((t["width"], t["height"], t["offset_x"], t["offset_y"], t["pyramid_level"],

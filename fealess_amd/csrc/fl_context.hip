@@ -175,6 +175,8 @@ static void free_device_tables(fl_detector *det)
   det->h_results = nullptr;
   for (auto &e : det->ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (det->d_jobs) { (void)hipFree(det->d_jobs); det->d_jobs = nullptr; }
+  det->selected_frames = 0;
   if (det->d_zoom) { (void)hipFree(det->d_zoom); det->d_zoom = nullptr; }
   if (det->d_zoom_src) { (void)hipFree(det->d_zoom_src); det->d_zoom_src = nullptr; det->zoom_src_bytes = 0; }
   for (int b = 0; b < 2; ++b) {
@@ -367,6 +369,12 @@ int fl_grow_candidates(fl_detector *det, int needed)
   if (want > (1ll << 28)) return fl_set_error(ctx, FL_ERR_OVERFLOW, "%d candidates in one frame", needed);
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int old_cap = det->cap;
+  // the frame workspaces (and with them any depth frames gathered into them) are about to be freed: nothing queued
+  // before this point may be refined afterwards
+  det->last_refinable = false;
+  det->last_depth_base = nullptr;
+  det->last_depth_stride = 0;
+  det->last_batch = 0;
   (void)hipFree(det->d_ws);
   det->d_ws = nullptr;
   int rc = layout_workspace(det, (int)want);
@@ -557,5 +565,8 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   for (auto &e : det->ev) FL_HIP(ctx, hipEventCreate(&e));
   det->finalized = true;
   det->last_batch = 0;
+  det->last_refinable = false;
+  det->last_depth_base = nullptr;
+  det->last_depth_stride = 0;
   return FL_OK;
 }

@@ -1761,6 +1761,7 @@ void k_icp_pipeline(IcpArgs a)
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
 
   fl_recognition_result *res = &a.results[job];
+  if (a.job.kind == 0 && a.jobs && frame < 0) return;    // fl_refine_selected: this frame's winner belongs to another rank (uniform per workgroup)
   const uint16_t *scene, *model;
   float r_match[9], t_match[3];
   bool model_01mm;

@@ -164,6 +164,12 @@ struct fl_detector {
   const uint16_t *last_depth_base = nullptr;   // the last batch's depth frames on the device (fl_refine_matches reads them)
   size_t last_depth_stride = 0;
   bool last_match_only = false;          // the last batch was fl_match_batch_submit (no ICP stage to time)
+  bool last_refinable = false;           // the last batch came from a batch submit (stage_and_match) and its depth frames are still where
+                                         // last_depth_base says: only then may fl_refine_matches / fl_export_topk_batch follow
+
+  // template-sharded recognition on the device: the jobs fl_select_best_batch chose (frame = -1: not this rank's)
+  FlRefineJob *d_jobs = nullptr;         // max_batch, allocated on first use
+  int selected_frames = 0;               // frames of the last fl_select_best_batch (0: none pending)
 
   // results
   fl_recognition_result *d_results = nullptr;   // max_batch

@@ -968,6 +968,23 @@ static bool grow_after_overflow(fl_detector *det, int n_frames, int attempt, int
   return true;
 }
 
+// The queued entry points cannot replay a batch themselves; their caller can: after a batch in which a frame reported
+// FL_ERR_OVERFLOW (fl_recognition_result.status, or FL_TOPK_OVERFLOW in the exported records), this waits for the stream,
+// grows the candidate buffers to what the fullest of the last batch's first n_frames frames needs, and the caller submits
+// the batch again.  *new_cap = the capacity afterwards (unchanged when no frame had overflowed).
+extern "C" int fl_detector_grow_candidates(fl_detector *det, int n_frames, int *new_cap)
+{
+  if (!det || n_frames <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames");
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  int needed = 0;
+  int rc = fl_overflow_needed(det, n_frames, &needed);
+  if (rc == FL_OK && needed > 0) rc = fl_grow_candidates(det, needed);
+  if (new_cap) *new_cap = det->cap;
+  return rc;
+}
+
 extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quantized, int mem, float threshold,
                                   fl_match *out, int cap, int *n_total)
 {
@@ -988,6 +1005,8 @@ extern "C" int fl_match_quantized(fl_detector *det, const uint8_t *const *quanti
     if (rc) return rc;
     det->last_batch = 1;
     det->last_from_images = false;
+    det->last_refinable = false;           // no depth frame belongs to this batch
+    det->last_depth_base = nullptr;
     rc = read_matches(det, 0, out, cap, n_total);
     if (!grow_after_overflow(det, 1, attempt, &rc)) return rc;
   }
@@ -1051,6 +1070,8 @@ static int match_frame_masked_once(fl_detector *det, const uint8_t *bgr, const u
   if (rc == FL_OK) {
     det->last_batch = 1;
     det->last_from_images = true;
+    det->last_refinable = false;           // single-frame Detector::match: fl_refine_matches belongs to fl_match_batch_submit
+    det->last_depth_base = nullptr;
     rc = read_matches(det, 0, out, cap, n_total);
   } else if (rc == FL_ERR_HIP) {
     fl_set_error(ctx, rc, "mask upload / k_apply_mask launch failed");
@@ -1211,13 +1232,15 @@ __global__ void k_export_topk_batch(const uint8_t *ws, size_t ws_stride, size_t 
                                     fl_match *out)
 {
   const uint8_t *w = ws + (size_t)blockIdx.x * ws_stride;
-  const int n = ((const int *)(w + off_count))[1];
+  const int *counters = (const int *)(w + off_count);
+  const bool over = counters[2] != 0;                      // the candidate buffers overflowed: the list is not the frame's list
+  const int n = over ? 0 : counters[1];
   const fl_match *m = (const fl_match *)(w + off_match);
   fl_match *o = out + (size_t)blockIdx.x * k;
   for (int i = threadIdx.x; i < k; i += blockDim.x) {
     fl_match r;
     if (i < n) { r = m[i]; r.template_id += tid_base; }
-    else { r.x = r.y = 0; r.similarity = 0.f; r.class_idx = -1; r.template_id = -1; }
+    else { r.x = r.y = 0; r.similarity = 0.f; r.class_idx = -1; r.template_id = (over && i == 0) ? FL_TOPK_OVERFLOW : -1; }
     o[i] = r;
   }
 }
@@ -1228,10 +1251,68 @@ extern "C" int fl_export_topk_batch(fl_detector *det, int n_frames, int k, int t
   if (!det || !dev_out || k <= 0 || n_frames <= 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
   if (!det->finalized || n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames");
+  if (n_frames > det->last_batch) return fl_set_error(ctx, FL_ERR_STATE, "%d frames asked for, the last batch had %d", n_frames, det->last_batch);
   FL_HIP(ctx, hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_export_topk_batch, dim3(n_frames), dim3(64), 0, ctx->stream, det->d_ws, det->ws_stride, det->off_count,
                      det->off_match, k, template_id_base, (fl_match *)dev_out);
   FL_HIP(ctx, hipGetLastError());
+  return FL_OK;
+}
+
+// Match::operator< (linemod.hpp:262-267: similarity descending, then template id ascending) extended to a total order
+// by (class, y, x) -- the comparator of fl_merge_topk
+__device__ __forceinline__ bool match_before(const fl_match &a, const fl_match &b)
+{
+  if (a.similarity != b.similarity) return a.similarity > b.similarity;
+  if (a.template_id != b.template_id) return a.template_id < b.template_id;
+  if (a.class_idx != b.class_idx) return a.class_idx < b.class_idx;
+  if (a.y != b.y) return a.y < b.y;
+  return a.x < b.x;
+}
+
+// one thread per frame: the best of the ranks' first records = matches[0] of the global sort; its refinement job if the
+// winner's template lies in this rank's slice
+__global__ __launch_bounds__(64) void k_select_best(const fl_match *__restrict__ gathered, int n_ranks, int n_frames, int k,
+                                                    int tid_first, int tid_count, fl_match *__restrict__ best, FlRefineJob *__restrict__ jobs)
+{
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= n_frames) return;
+  fl_match b;
+  b.x = b.y = 0; b.similarity = 0.f; b.class_idx = -1; b.template_id = -1;
+  bool over = false;
+  for (int r = 0; r < n_ranks; ++r) {
+    const fl_match m = gathered[((size_t)r * n_frames + f) * k];
+    if (m.template_id == FL_TOPK_OVERFLOW) over = true;
+    else if (m.template_id >= 0 && (b.template_id < 0 || match_before(m, b))) b = m;
+  }
+  if (over) { b.x = b.y = 0; b.similarity = 0.f; b.class_idx = -1; b.template_id = FL_TOPK_OVERFLOW; }
+  best[f] = b;
+  FlRefineJob j;
+  j.frame = -1;
+  j.match = b;
+  if (b.template_id >= tid_first && b.template_id < tid_first + tid_count) {
+    j.frame = f;
+    j.match.template_id = b.template_id - tid_first;      // class-local on this rank's detector
+  }
+  jobs[f] = j;
+}
+
+extern "C" int fl_select_best_batch(fl_detector *det, const void *dev_gathered, int n_ranks, int n_frames, int k, int tid_first,
+                                    int tid_count, void *dev_best)
+{
+  if (!det || !dev_gathered || !dev_best || n_ranks <= 0 || n_frames <= 0 || k <= 0 || tid_first < 0 || tid_count < 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized) return fl_set_error(ctx, FL_ERR_STATE, "fl_detector_finalize first");
+  if (n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames %d > max_batch %d", n_frames, det->max_batch);
+  if (det->classes.size() != 1 || tid_count != det->classes[0].n_pyramids)
+    return fl_set_error(ctx, FL_ERR_INVALID, "template-sharded refinement: one class per detector, tid_count = its %d pyramids",
+                        det->classes.empty() ? 0 : det->classes[0].n_pyramids);
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  if (!det->d_jobs) FL_HIP(ctx, hipMalloc((void **)&det->d_jobs, sizeof(FlRefineJob) * (size_t)det->max_batch));
+  hipLaunchKernelGGL(k_select_best, dim3((n_frames + 63) / 64), dim3(64), 0, ctx->stream, (const fl_match *)dev_gathered, n_ranks,
+                     n_frames, k, tid_first, tid_count, (fl_match *)dev_best, det->d_jobs);
+  FL_HIP(ctx, hipGetLastError());
+  det->selected_frames = n_frames;
   return FL_OK;
 }
 

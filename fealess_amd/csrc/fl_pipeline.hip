@@ -103,6 +103,7 @@ static int stage_and_match(fl_detector *det, int n_frames, const uint8_t *const 
   *depth_stride_out = depth_stride;
   det->last_depth_base = depth_base;
   det->last_depth_stride = depth_stride;
+  det->last_refinable = depth != nullptr;  // fl_refine_matches runs the ICP half: it needs the batch's depth frames
   *host_buf_out = host_buf;
   return FL_OK;
 }
@@ -275,7 +276,9 @@ extern "C" int fl_refine_matches(fl_detector *det, int n_jobs, const int32_t *fr
 {
   if (!det || !frames || !matches || !K || !params || !results || n_jobs <= 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
-  if (!det->finalized || det->last_batch < 1 || !det->last_from_images || (det->M == 2 && !det->last_depth_base))
+  // only a batch submit leaves the depth frames of the batch where last_depth_base says; fl_match_frame*, fl_match_quantized,
+  // fl_recognize_topk and a candidate-buffer growth (which frees the frame workspaces) all clear last_refinable
+  if (!det->finalized || det->last_batch < 1 || !det->last_from_images || !det->last_refinable || !det->last_depth_base)
     return fl_set_error(ctx, FL_ERR_STATE, "fl_match_batch_submit first");
   if (n_jobs > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_jobs %d > max_batch %d", n_jobs, det->max_batch);
   if (K->width != det->w0 || K->height != det->h0) return fl_set_error(ctx, FL_ERR_INVALID, "intrinsics size");
@@ -300,6 +303,43 @@ extern "C" int fl_refine_matches(fl_detector *det, int n_jobs, const int32_t *fr
   FL_HIP(ctx, hipMemcpyAsync(det->h_results, det->d_results, sizeof(fl_recognition_result) * (size_t)n_jobs, hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));          // also covers the pageable `jobs` upload
   memcpy(results, det->h_results, sizeof(fl_recognition_result) * (size_t)n_jobs);
+  return FL_OK;
+}
+
+// {found, 4x4 pose} rows of a batch of results, for the ranks' exchange (template-sharded recognition)
+__global__ __launch_bounds__(64) void k_pack_pose_rows(const fl_recognition_result *__restrict__ res, int n, float *__restrict__ rows)
+{
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const int t = threadIdx.x;
+  if (t == 0) rows[(size_t)f * 17] = res[f].found ? 1.0f : 0.0f;
+  else if (t <= 16) rows[(size_t)f * 17 + t] = res[f].found ? res[f].pose[t - 1] : 0.0f;
+}
+
+// The device-side twin of fl_refine_matches: the jobs fl_select_best_batch left in det->d_jobs (frame = -1: not ours, the
+// workgroup exits), results packed as rows for the exchange; nothing here touches the host.
+extern "C" int fl_refine_selected(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *params,
+                                  const uint16_t *depth_base, size_t depth_stride, float *dev_rows)
+{
+  if (!det || !K || !params || !dev_rows || n_frames <= 0) return FL_ERR_INVALID;
+  fl_context *ctx = det->ctx;
+  if (!det->finalized || !det->d_jobs || det->selected_frames != n_frames)
+    return fl_set_error(ctx, FL_ERR_STATE, "fl_select_best_batch for these %d frames first", n_frames);
+  if (K->width != det->w0 || K->height != det->h0) return fl_set_error(ctx, FL_ERR_INVALID, "intrinsics size");
+  if (!depth_base) {
+    if (!det->last_refinable || !det->last_depth_base || n_frames > det->last_batch)
+      return fl_set_error(ctx, FL_ERR_STATE, "no depth frames given and fl_match_batch_submit did not leave any");
+    depth_base = det->last_depth_base;
+    depth_stride = det->last_depth_stride;
+  }
+  FL_HIP(ctx, hipSetDevice(ctx->device));
+  FL_HIP(ctx, hipMemsetAsync(det->d_results, 0, sizeof(fl_recognition_result) * (size_t)n_frames, ctx->stream));
+  det->have_times = false;
+  int rc = fl_launch_detection_jobs(det, n_frames, det->d_jobs, K, params, depth_base, depth_stride);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pack_pose_rows, dim3(n_frames), dim3(64), 0, ctx->stream, det->d_results, n_frames, dev_rows);
+  FL_HIP(ctx, hipGetLastError());
+  det->selected_frames = 0;
   return FL_OK;
 }
 
@@ -333,6 +373,8 @@ static int recognize_topk_once(fl_detector *det, const uint8_t *bgr, const uint1
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   det->last_batch = 1;
   det->last_from_images = true;
+  det->last_refinable = false;             // the frame lives in workspace 0 only until the next call: not a batch to refine later
+  det->last_depth_base = nullptr;
   if (results[0].status == FL_ERR_OVERFLOW) return fl_set_error(ctx, FL_ERR_OVERFLOW, "more than %d candidates in the frame", det->cap);
   const int n = results[0].n_matches < k ? results[0].n_matches : k;
   *n_results = n < 0 ? 0 : n;

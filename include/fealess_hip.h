@@ -158,6 +158,12 @@ int  fl_detector_finalize(fl_detector *det, int w0, int h0, int max_batch, int m
  * (linemod.cpp:1490-1504, 1575); the queued ones (fl_recognize_submit / fl_match_batch_submit) cannot replay a batch and
  * report FL_ERR_OVERFLOW in that frame's status (the other frames keep their results).  < 0: a hard cap of
  * -max_candidates, FL_ERR_OVERFLOW beyond it. */
+/* For the QUEUED entry points (fl_recognize_submit, fl_match_batch_submit), which cannot replay a batch themselves: after
+ * a batch in which a frame reported FL_ERR_OVERFLOW (fl_recognition_result.status, or FL_TOPK_OVERFLOW in the records of
+ * fl_export_topk_batch), waits for the stream and grows the candidate buffers to what the fullest of the last batch's
+ * first n_frames frames needs -- the std::vector growth of linemod.cpp:1490-1504 -- so that the caller can submit the
+ * batch again.  *new_cap (may be NULL) = the capacity afterwards.  FL_ERR_OVERFLOW under a hard cap / without memory. */
+int  fl_detector_grow_candidates(fl_detector *det, int n_frames, int *new_cap);
 /* Detector::match's `class_ids` argument (linemod.hpp:319-327, linemod.cpp:1418-1434): n = 0 matches every
  * class (the default, and what Recognition passes); otherwise only the listed classes that exist.
  * Sticky until changed; may be called before or after fl_detector_finalize. */
@@ -288,7 +294,11 @@ int  fl_nms(const fl_recognition_result *objs, int n, float th_obj_dist, int *wi
  * all-gather by the caller; template ids are offset by template_id_base (the shard's first
  * global id).  Queued on the context's stream, no synchronisation. */
 int  fl_export_topk(fl_detector *det, int frame, int k, int template_id_base, void *dev_out);
-/* the same for every frame of the last batch in one launch: dev_out[frame * k + i] */
+/* the same for every frame of the last batch in one launch: dev_out[frame * k + i].
+ * A frame whose candidate buffers overflowed (its list is truncated in an order that depends on atomics) is exported as
+ * record 0 = {template_id = FL_TOPK_OVERFLOW, class_idx = -1} and padding: the flag travels with the all-gather, so every
+ * rank sees it (fl_select_best_batch turns it into that frame's status; the host merge ignores records with ids < 0). */
+#define FL_TOPK_OVERFLOW (-2)
 int  fl_export_topk_batch(fl_detector *det, int n_frames, int k, int template_id_base, void *dev_out);
 /* merge n_ranks*k gathered records (host) exactly as one Detector::match over the union would
  * order them; returns the number written to out (<= cap). */
@@ -304,6 +314,22 @@ int  fl_merge_topk_batch(const fl_match *gathered, int n_ranks, int n_frames, in
  * matches[j].template_id is class-local on THIS detector; results[j] (host) as fl_recognize_batch fills them. */
 int  fl_refine_matches(fl_detector *det, int n_jobs, const int32_t *frames, const fl_match *matches, const fl_intrinsics *K,
                        const fl_recognition_params *params, fl_recognition_result *results);
+/* The same hand-over without leaving the device (no host round trip between Detector::match and the ICP):
+ * fl_select_best_batch reads the all-gathered records IN DEVICE MEMORY (dev_gathered[(rank * n_frames + frame) * k + i],
+ * global template ids) and writes, per frame, matches[0] of one global std::sort + std::unique over all ranks' lists
+ * (linemod.cpp:1437-1439, Match::operator< linemod.hpp:262-267; Recognition() uses nothing else, obj_reco_lmicp.cpp:111)
+ * to dev_best[frame] (global ids; template_id = -1: no rank matched; FL_TOPK_OVERFLOW: some rank's list overflowed) --
+ * every list is sorted, so it is the best of the ranks' first records.  Frames whose winner lies in this rank's slice
+ * [tid_first, tid_first + tid_count) become the detector's pending refinement jobs.
+ * fl_refine_selected then runs the second half of Recognition() for those jobs (one launch over n_frames workgroups,
+ * the ones without a job exit at once) and writes dev_rows[frame][17] = {found, row-major 4x4 pose} as float32, zeros
+ * for the frames this rank does not own (a sum or a gather over the ranks gives every frame's pose).  depth_base /
+ * depth_stride (bytes) locate the batch's depth frames on the device; NULL / 0 = where fl_match_batch_submit left them.
+ * Both are queued on the context's stream without synchronisation. */
+int  fl_select_best_batch(fl_detector *det, const void *dev_gathered, int n_ranks, int n_frames, int k, int tid_first,
+                          int tid_count, void *dev_best);
+int  fl_refine_selected(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *params,
+                        const uint16_t *depth_base, size_t depth_stride, float *dev_rows);
 
 /* diagnostics: per-frame counters of the last match {coarse candidates, matches after sort/unique,
  * overflow flag, 0} (host memory) */

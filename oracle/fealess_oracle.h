@@ -171,6 +171,9 @@ int  orc_recognition(const uint8_t *bgr, const uint16_t *depth, int w, int h,
                      const float *poses13, const uint16_t *const *model_depths_01mm,
                      float threshold, int icp_it_thr, float dist_mean_thr, float dist_diff_thr,
                      int accum64, int use_kdtree, orc_recognition_result *res);
+/* stage times (ms) of the calling thread's last orc_recognition at the reference's own timer points:
+ * [0] "Time of linemod" (CadReco/obj_reco_lmicp.cpp:88,124-125), [1] "Time of ICP" (:126,201-202) */
+void orc_last_stage_ms(double out[2]);
 
 /* multi-hypothesis refinement + nonMaximumSuppression (ICP/NMS.cpp:6-40, obj_data.h) */
 int orc_recognition_topk(const uint8_t *bgr, const uint16_t *depth, int w, int h, double fx, double fy, double cx, double cy,

@@ -195,7 +195,7 @@ void orc_median5(const uint8_t *src, int w, int h, uint8_t *dst)
  * does not depend on its first (z) index; entry [z][y][x] = 1 << k where k is the first of the 8
  * directions (cos, sin)(k*45 deg) maximising (x-10)*cos + (y-10)*sin.  Regenerated from that
  * rule (tan 22.5 deg is irrational, so integer offsets never tie except at the centre);
- * tests/test_oracle_tables.py checks all 8000 bytes against the reference text when present. */
+ * tests/test_oracle_cpu.py::test_tables_equal_reference_text checks all 8000 bytes against the reference text when present. */
 void orc_normal_lut(uint8_t lut[8000])
 {
   for (int y = 0; y < 20; ++y)

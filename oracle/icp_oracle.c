@@ -10,8 +10,10 @@
  * Build with -ffp-contract=off: each float expression is one IEEE binary32 operation per
  * operator, in the order written (the reference is built for baseline x86-64: no FMA).
  */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime under -std=c99 */
 #include "fealess_oracle.h"
 #include <math.h>
+#include <time.h>
 #include <float.h>
 #include <stdlib.h>
 #include <string.h>
@@ -500,6 +502,15 @@ int orc_detection(const uint16_t *model_depth, const uint16_t *scene_depth, int 
 
 /* CObjRecoLmICP::Recognition (CadReco/obj_reco_lmicp.cpp:86-204), input already 640 wide */
 /* the part of Recognition() after the match has been chosen (obj_reco_lmicp.cpp:111-197) */
+/* wall clock of the stage timers (cv::getTickCount in the reference) */
+static __thread double orc_stage_ms[2];
+static double stage_clock_ms(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
 static int recognition_refine(const orc_match best, const uint16_t *depth, int w, int h, double fx, double fy, double cx, double cy,
                               const orc_bank *bank, const float *poses13, const uint16_t *const *model_depths_01mm,
                               int icp_it_thr, float dist_mean_thr, float dist_diff_thr, int accum64, int use_kdtree,
@@ -547,12 +558,27 @@ int orc_recognition(const uint8_t *bgr, const uint16_t *depth, int w, int h,
   memset(res, 0, sizeof(*res));
   orc_match best;
   int n_total = 0;
+  /* the reference's own timer points: "Time of linemod" = Detector::match (obj_reco_lmicp.cpp:88,124-125),
+   * "Time of ICP" = everything after it up to the pose (:126,201-202) */
+  const double t0 = stage_clock_ms();
+  orc_stage_ms[0] = orc_stage_ms[1] = 0.0;
   int n = orc_match_images(bgr, depth, w, h, levels, T_at_level, bank, 1, threshold, &best, 1, &n_total, NULL);
+  const double t1 = stage_clock_ms();
+  orc_stage_ms[0] = t1 - t0;
   if (n < 0) return -1;                                  /* ERROR_INVALID_PARAM :102-105 */
   res->n_matches = n_total;
   if (n == 0) return 0;                                  /* :106-109 */
-  return recognition_refine(best, depth, w, h, fx, fy, cx, cy, bank, poses13, model_depths_01mm, icp_it_thr, dist_mean_thr,
-                            dist_diff_thr, accum64, use_kdtree, res);
+  const int rc = recognition_refine(best, depth, w, h, fx, fy, cx, cy, bank, poses13, model_depths_01mm, icp_it_thr, dist_mean_thr,
+                                    dist_diff_thr, accum64, use_kdtree, res);
+  orc_stage_ms[1] = stage_clock_ms() - t1;
+  return rc;
+}
+
+/* the two stage times (ms) of the calling thread's last orc_recognition: [0] "Time of linemod", [1] "Time of ICP" */
+void orc_last_stage_ms(double out[2])
+{
+  out[0] = orc_stage_ms[0];
+  out[1] = orc_stage_ms[1];
 }
 
 /* SURVEY 8f rank 3 -- the multi-hypothesis pipeline the reference's dead code sketches: the same refinement for the

@@ -12,7 +12,7 @@
  * set of spread orientations = max over set bits i of g(circular distance(i, ori)) with
  * g(0)=4, g(1)=2, g(2)=1, else 0; entry [32*ori + n] covers the low nibble n (bits 0-3), entry
  * [32*ori + 16 + n] the high nibble (bits 4-7).  Regenerated here from that rule; the unit test
- * tests/test_oracle_tables.py checks it byte for byte against the reference text when present. */
+ * tests/test_oracle_cpu.py::test_tables_equal_reference_text checks it byte for byte against the reference text when present. */
 void orc_similarity_lut(uint8_t lut[256])
 {
   static const uint8_t g[8] = {4, 2, 1, 0, 0, 0, 1, 2};

@@ -345,10 +345,9 @@ def recognition(bgr, depth, K, T_pyramid, bank, threshold=75.0, icp_it_thr=10, d
     T = (C.c_int * levels)(*T_pyramid)
     arr, keep = _banks([bank])
     t, f, p = keep[0]
-    mds = [np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
-    if len(mds) < bank.n_pyramids:        # pyramids without a depth render (bank.py): an empty render, as the product uploads
-        zero = np.zeros((h, w), np.uint16)
-        mds = mds + [zero] * (bank.n_pyramids - len(mds))
+    zero = np.zeros((h, w), np.uint16)    # pyramids without a depth render (bank.py): an empty render, as the product uploads
+    mds = [zero if m is None else np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
+    mds = mds + [zero] * (bank.n_pyramids - len(mds))
     mptr = (C.c_void_p * len(mds))(*[m.ctypes.data for m in mds])
     res = OrcRecognitionResult()
     rc = lib().orc_recognition(_p(b), _p(d), w, h, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
@@ -362,6 +361,14 @@ def recognition(bgr, depth, K, T_pyramid, bank, threshold=75.0, icp_it_thr=10, d
                 det=dict(R_final=np.array(res.det.R_final, np.float32).reshape(3, 3),
                          T_final=np.array(res.det.T_final, np.float32), icp=_icp_dict(res.det.icp),
                          n_points=int(res.det.n_points)))
+
+
+def last_stage_ms():
+    """(linemod_ms, icp_ms) of the calling thread's last recognition(): the reference's own timer points
+    ("Time of linemod" / "Time of ICP", CadReco/obj_reco_lmicp.cpp:125,202)."""
+    out = (C.c_double * 2)()
+    lib().orc_last_stage_ms(out)
+    return float(out[0]), float(out[1])
 
 
 def _reco_dict(res, rc=0):
@@ -384,10 +391,9 @@ def recognition_topk(bgr, depth, K, T_pyramid, bank, k, threshold=75.0, icp_it_t
     T = (C.c_int * levels)(*T_pyramid)
     arr, keep = _banks([bank])
     t, f, p = keep[0]
-    mds = [np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
-    if len(mds) < bank.n_pyramids:
-        zero = np.zeros((h, w), np.uint16)
-        mds = mds + [zero] * (bank.n_pyramids - len(mds))
+    zero = np.zeros((h, w), np.uint16)    # pyramids without a depth render (bank.py): an empty render, as the product uploads
+    mds = [zero if m is None else np.ascontiguousarray(m, np.uint16) for m in bank.model_depths]
+    mds = mds + [zero] * (bank.n_pyramids - len(mds))
     mptr = (C.c_void_p * len(mds))(*[m.ctypes.data for m in mds])
     res = (OrcRecognitionResult * k)()
     n = lib().orc_recognition_topk(_p(b), _p(d), w, h, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),

@@ -216,3 +216,43 @@ def test_cadreco_factory_rejects_unsupported_types():
     lib.cadreco_create.restype = C.c_void_p
     for unsupported in (0, 2, 3):            # EObjReco_FEATURE, BB8, PoseNet -> nullptr (obj_reco_temp.cpp:13-30)
         assert not lib.cadreco_create(unsupported)
+
+
+def test_bank_depth_renders_stay_with_their_pyramids():
+    """model_depths[i] is the render of pyramid i: a render added after pyramids without one must not slide down to an
+    earlier pyramid (api.finalize uploads by index, subset() copies by index)."""
+    from fealess_amd import synth
+    from fealess_amd.bank import TemplateBank
+    rng = np.random.default_rng(0)
+    bank = TemplateBank("obj", 2, 2)
+    d0 = np.full((480, 640), 7, np.uint16)
+    d3 = np.full((480, 640), 9, np.uint16)
+    bank.add_pyramid(synth.random_pyramid(rng, 2, 2, 640, 480), None, d0)
+    bank.add_pyramid(synth.random_pyramid(rng, 2, 2, 640, 480), None, None)
+    bank.add_pyramid(synth.random_pyramid(rng, 2, 2, 640, 480), None, None)
+    bank.add_pyramid(synth.random_pyramid(rng, 2, 2, 640, 480), None, d3)
+    bank.add_pyramid(synth.random_pyramid(rng, 2, 2, 640, 480), None, None)
+    assert bank.n_pyramids == 5 and len(bank.model_depths) == 4
+    assert bank.model_depths[0][0, 0] == 7 and bank.model_depths[1] is None and bank.model_depths[2] is None and bank.model_depths[3][0, 0] == 9
+    sub = bank.subset(2, 3)
+    assert sub.n_pyramids == 3 and sub.model_depths[0] is None and sub.model_depths[1][0, 0] == 9 and len(sub.model_depths) == 2
+
+
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no WORLD_SIZE) must run TWO ranks: the parent starts torch.distributed.run
+    as a child and relays rank 0's line; inside a rank a WORLD_SIZE that differs from --gpus fails loudly.  --launch-check
+    keeps the GPU out of it (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["collectives"]["ranks"] == 2
+    env["WORLD_SIZE"] = "1"
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr

@@ -154,7 +154,7 @@ def test_c3_match_from_images_1280x720_three_levels(ctx, oracle):
             ex = ctx.extract_template_pyramid(bgr_v, d_bg, (mask * 255).astype(np.uint8), 3)
             assert ex is not None
             bank.add_pyramid(ex[0], synth.pose13(dR @ Rs, tv), None)
-    while bank.n_pyramids < 40:
+    while bank.n_pyramids < 240:                                  # 4 trained views + 236 random pyramids
         bank.add_pyramid(synth.random_pyramid(rng, 3, 2, w, h), None, None)
     det = api.Detector(ctx, 2, T)
     det.add_class(bank)

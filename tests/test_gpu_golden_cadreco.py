@@ -176,29 +176,56 @@ def test_template_sharded_topk_on_one_gpu(ctx, oracle):
     assert merged.tobytes() == full[:len(merged)].tobytes()
 
 
-def test_template_sharded_recognition_two_ranks_on_one_gpu(tmp_path):
-    """BASELINE configs[3] rehearsed on one GPU: two processes, each holding half of the bank, gloo in place of RCCL
-    (two RCCL ranks cannot share a device), `bench.py --shard templates --verify-sharded`: every frame's best match and
-    pose must equal, bit for bit, what one detector over the whole bank returns from fl_recognize_batch."""
+def _run_bench(argv, timeout=900):
     import json
-    import socket
     import subprocess
     import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shard", "templates", "--share-device",
-           "--verify-sharded", "--templates", "30", "--batch", "6", "--scenes", "3", "--steps", "1", "--warmup", "0", "--icp-iters", "8",
-           "--topk", "16"]
-    env = dict(os.environ)
-    env.pop("FL_DEV_POISON", None)
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FL_DEV_POISON")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+SHARDED = ["--gpus", "2", "--shard", "templates", "--share-device", "--verify-sharded", "--templates", "30", "--batch", "6", "--scenes", "3",
+           "--steps", "3", "--warmup", "1", "--icp-iters", "8", "--topk", "16"]
+
+
+def test_template_sharded_recognition_two_ranks_on_one_gpu():
+    """BASELINE configs[3] rehearsed on one GPU: two processes, each holding half of the bank, gloo in place of RCCL
+    (two RCCL ranks cannot share a device), `bench.py --gpus 2 --shard templates --verify-sharded` STARTED PLAINLY (the parent
+    launches the two ranks itself): every frame's best match and pose must equal, bit for bit, what one detector over the
+    whole bank returns from fl_recognize_batch.  The device path runs: fl_export_topk_batch -> all-gather ->
+    fl_select_best_batch -> fl_refine_selected -> int32 all-reduce of the pose rows, pipelined over three steps."""
+    out = _run_bench(SHARDED)
     assert out["n_gpus"] == 2 and out["config"]["templates_total"] == 60
     assert out["verified_against_single_detector"] is True, out
     assert out["detections"] == "6/6"
-    assert out["collectives"]["ranks"] == 2
+    assert out["collectives"]["ranks"] == 2 and out["collectives"]["path"].startswith("device")
+    assert min(out["winner_owner_histogram"]) > 0                   # both ranks own winners: both refined
+
+
+def test_template_sharded_host_merge_path_gives_the_same(tmp_path):
+    """the round-2 path (numpy merge on the host, fl_refine_matches) stays available and equal"""
+    out = _run_bench(SHARDED + ["--sharded-host-merge"])
+    assert out["verified_against_single_detector"] is True, out
+    assert out["collectives"]["path"].startswith("host")
+
+
+def test_template_sharded_overflow_is_seen_by_every_rank_and_grown():
+    """Candidate buffers of 64 entries and a threshold that makes every non-zero coarse cell a candidate: every frame
+    overflows on both ranks.  The exported records carry the flag through the all-gather, every rank grows its buffers
+    (fl_detector_grow_candidates) and the step runs again; the result still equals the single detector's, and no truncated
+    list is ever refined."""
+    out = _run_bench(SHARDED + ["--max-candidates", "64", "--match-threshold", "-100"])
+    assert out["verified_against_single_detector"] is True, out
+    assert out["config"]["candidate_capacity"] > 64
+
+
+def test_template_sharded_single_rank_line_has_roofline_and_cpu_baseline():
+    out = _run_bench(["--shard", "templates", "--templates", "40", "--batch", "8", "--scenes", "3", "--steps", "3", "--warmup", "1",
+                      "--icp-iters", "8", "--topk", "16", "--cpu-seconds", "2", "--compare-host-merge", "--verify-sharded"])
+    assert out["n_gpus"] == 1 and out["verified_against_single_detector"] is True
+    assert out["roofline"] is not None and out["roofline"]["launch_ms"] > 0 and out["cpu_baseline"]["value"] > 0
+    assert out["collectives"]["host_syncs_per_step"] <= 1.5
+    assert out["collectives"]["host_merge_comparison"]["same_result"] is True

@@ -230,3 +230,40 @@ def test_match_property_full_size(ctx):
             assert abs(int(m["x"]) - int(hdr["offset_x"])) <= 5 and abs(int(m["y"]) - int(hdr["offset_y"])) <= 5
     assert hits >= 10
     det.close()
+
+
+def test_match_property_full_size_1280x720_three_levels(ctx):
+    """BASELINE configs[2] at full size (1280x720, 2000 templates, T = {5, 8, 4}: linearize needs rows/cols % T == 0,
+    linemod.cpp:1062-1063, and 320x180 is not divisible by 8 -- SURVEY M4): the 720p twin of
+    test_match_property_full_size.  Planted templates must be found at their planted position with similarity 100
+    through all three levels of refinement (linemod.cpp:1509-1573), the list sorted and duplicate-free
+    (linemod.cpp:1437-1439)."""
+    rng = np.random.default_rng(78)
+    w0, h0, T = 1280, 720, [5, 8, 4]
+    qs = _quant_pyramid(rng, w0, h0, 3, 2, density=0.03)
+    bank = synth.make_bank("obj", 2000, 3, 2, w0, h0, seed=13, qs=qs, planted_frac=0.01)
+    det = api.Detector(ctx, 2, T)
+    det.add_class(bank)
+    det.finalize(w0, h0)
+    got, n = det.match_quantized(qs, 90.0)
+    assert n > 0 and len(got) == n
+    sim = got["similarity"]
+    assert np.all(sim[:-1] >= sim[1:])
+    tid = got["template_id"]
+    same_sim = sim[:-1] == sim[1:]
+    assert np.all(tid[:-1][same_sim] <= tid[1:][same_sim])          # Match::operator< : similarity desc, then template id asc
+    key = np.stack([got["x"], got["y"], sim.view(np.int32)], 1)
+    assert not np.any(np.all(key[1:] == key[:-1], axis=1))
+    assert np.all(sim >= 90.0)                                      # refined matches below the threshold are erased (:1566-1570)
+    t, f, p = bank.arrays()
+    best = {}
+    for m in got:
+        best.setdefault(int(m["template_id"]), m)
+    hits = 0
+    for tid_, m in best.items():
+        hdr = t[tid_ * 6]                                            # [l * M + m] per pyramid: 3 levels x 2 modalities
+        if m["similarity"] == 100.0:
+            hits += 1
+            assert abs(int(m["x"]) - int(hdr["offset_x"])) <= 5 and abs(int(m["y"]) - int(hdr["offset_y"])) <= 5
+    assert hits >= 10
+    det.close()

@@ -122,6 +122,41 @@ def _worker_recognize(rank, world, port, out_dir):
         ok = ok and np.array_equal(poses[f, 1:].view(np.uint32), e["pose"].reshape(-1).astype(np.float32).view(np.uint32))
         ok = ok and n_out[f] == min(k, e["n_matches"])
         owners.append(D.owner_of(int(best["template_id"][f]), n, world))
+    # A candidate-buffer overflow on ONE rank (fl_export_topk_batch marks the frame's record 0 with TOPK_OVERFLOW): the flag
+    # travels with the all-gather, so both ranks see it.  Without a grow callable the frame is reported as failed (no pose,
+    # nothing refined from a truncated list); with one, every rank grows and the step runs again to the same result.
+    state = {"grown": 0, "calls": 0}
+
+    def local_topk_overflowing():
+        out = local_topk()
+        state["calls"] += 1
+        if rank == 1 and not state["grown"]:
+            out[1] = D.pad_topk(np.zeros(0, MATCH_DTYPE), k)
+            out[1]["template_id"][0] = D.TOPK_OVERFLOW
+        return out
+
+    def refine_checked(fr, matches):
+        assert (matches["template_id"] >= 0).all()
+        return refine(fr, matches)
+
+    b2, _, p2 = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk_overflowing, allgather, refine_checked, allreduce_sum)
+    ok = ok and int(b2["template_id"][1]) == D.TOPK_OVERFLOW and p2[1, 0] == 0.0 and not p2[1].any()
+    ok = ok and int(b2["template_id"][0]) == int(best["template_id"][0]) and np.array_equal(p2[0].view(np.uint32), poses[0].view(np.uint32))
+
+    def grow():
+        state["grown"] += 1
+
+    state["calls"] = 0
+    b3, _, p3 = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk_overflowing, allgather, refine_checked, allreduce_sum, grow=grow)
+    ok = ok and state["grown"] == 1 and state["calls"] == 2          # both ranks grew once and ran the step twice
+    ok = ok and b3.tobytes() == best.tobytes() and np.array_equal(p3.view(np.uint32), poses.view(np.uint32))
+    # the pose rows travel as int32 bit patterns: a -0.0 of the owner survives the exchange (a float sum would give +0.0)
+    z = np.zeros((1, 17), np.float32)
+    if rank == 0:
+        z[0, 3] = -0.0
+        z[0, 0] = 1.0
+    tot = allreduce_sum(z.view(np.int32)).view(np.float32)
+    ok = ok and np.signbit(tot[0, 3]) and tot[0, 0] == 1.0
     with open(os.path.join(out_dir, f"reco{rank}.txt"), "w") as fh:
         fh.write(f"{int(ok)} {owners}\n")
     dist.barrier()
