@@ -400,6 +400,11 @@ def main():
         print("icp organised search per frame: steps %.0f, positions per step %.1f (iterations 1-3: %.0f%% of all), fallback steps %.1f%%, "
               "staged points per step %.0f" % (st[0], st[1] / max(st[0], 1), 100 * st[4] / max(st[1], 1), 100 * st[2] / max(st[0], 1),
                                                 st[3] / max(st[0], 1)), file=sys.stderr)
+        hs = np.array([list(r.pose) + list(r.det.R_final) + list(r.det.T_final) for r in res]).sum(0)
+        tot = max(hs[:16].sum(), 1)
+        print("icp union classes %% of steps, rows W<=13,<=29,<=61,>61 x cols H<=5,<=10,<=20,>20: %s | largest lane window height 1..9+: %s | "
+              "width <=4,<=8,<=12: %s" % (np.round(100 * hs[:16].reshape(4, 4) / tot, 1).tolist(), np.round(100 * hs[16:25] / tot, 1).tolist(),
+                                          np.round(100 * hs[25:28] / tot, 1).tolist()), file=sys.stderr)
     if os.environ.get("FL_BENCH_NPTS") and args.config != "c3":            # dev aid: how uneven are the jobs of one ICP launch?
         npt = np.array([int(r.det.n_points) for r in res if r.found])
         print("icp n_points: found %d of %d, min / median / mean / max %d / %d / %d / %d, p5 / p95 %d / %d" %

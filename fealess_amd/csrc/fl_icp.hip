@@ -96,6 +96,12 @@
 #define FL_ICP_SPEC 1             // parity mode, organised search: the next iteration's search runs while the chain wave adds dist_mean
                                   // (1: in the 1024-thread kernel, 2: in both, 0: off)
 #endif
+#ifndef FL_ICP_SEARCH
+#define FL_ICP_SEARCH 2           // organised search, the step's overhead around the distance scan: 1 = round 2 (union window staged at its
+                                  // own width, six serial wave reductions), 2 = staged rows of 16 / 32 / 64 points (no address arithmetic
+                                  // per staged point), five interleaved reductions, batches per row by ballot
+#endif
+#define ICP_STAGE_CAP 384         // points a wave stages per search step (FL_ICP_SEARCH 2): six passes of 64
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
@@ -217,6 +223,7 @@ struct IcpSharedT {
   alignas(16) float dchain[2][ICP_DT];   // the deferred dist_mean chain's staging (chain wave only)
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
+  unsigned hist[40];                    // organised search: [0,16) union (W class x H class), [16,26) largest lane window height, [26,30) width class
 #endif
 };
 
@@ -741,6 +748,34 @@ struct OrgGeom {
 __device__ __forceinline__ int wave_min_i(int v) { FL_DPP_RED(min, 0x7fffffff) }
 __device__ __forceinline__ int wave_max_i(int v) { FL_DPP_RED(max, (int)0x80000000) }
 
+// N whole-wave maxima at once (a minimum is the maximum of the negated values): the DPP steps of the N reductions are
+// interleaved, so the wait states a DPP read needs after the VALU write of its source are filled by the other reductions'
+// steps instead of s_nop -- six serial reductions cost 6 x (6 + 6 nops + 2) issue slots, five interleaved ones 5 x 7
+template <int N>
+__device__ __forceinline__ void wave_max_multi(int (&v)[N])
+{
+#define FL_DPP_STEP(CTRL, RMASK)                                                                                       \
+  _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_)                                                                     \
+    v[k_] = max(v[k_], __builtin_amdgcn_update_dpp((int)0x80000000, v[k_], CTRL, RMASK, 0xF, false));
+  FL_DPP_STEP(0x111, 0xF)
+  FL_DPP_STEP(0x112, 0xF)
+  FL_DPP_STEP(0x114, 0xF)
+  FL_DPP_STEP(0x118, 0xF)
+  FL_DPP_STEP(0x142, 0xA)
+  FL_DPP_STEP(0x143, 0xC)
+#undef FL_DPP_STEP
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = __builtin_amdgcn_readlane(v[k], 63);
+}
+
+// float -> int as the hardware converts: saturating, NaN -> 0 (a C cast of an out-of-range value is undefined)
+__device__ __forceinline__ int cvt_i32_sat(float f)
+{
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
+
 // The crop pixels whose points can lie within distance r of q: a point (X, Y, Z) of pixel (su, sv) satisfies
 // su - cx = X fx / Z up to float rounding (it was generated as X = ((su - cx) / fx) Z), and |X - qx|, |Z - qz| <= r.
 // The 0.01-pixel slop is an order of magnitude above that rounding (5e-7 relative on |su - cx| <= 2000 pixels).  An empty window has u_lo > u_hi.
@@ -767,6 +802,28 @@ __device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy,
     v_lo = max(ivl, 0);
     v_hi = min(ivh, g.ch - 1);
   }
+}
+
+// org_window with the constants folded and the clamps left to the saturating conversion: returns whether the window holds a pixel.
+// cul / cuh = offu +- slop, cvl / cvh = offv +- slop (wave-uniform)
+__device__ __forceinline__ bool org_window2(const OrgGeom &g, float cul, float cuh, float cvl, float cvh, float qx, float qy, float qz, float r,
+                                            int &u_lo, int &u_hi, int &v_lo, int &v_hi)
+{
+  u_lo = 0; u_hi = g.cw - 1; v_lo = 0; v_hi = g.ch - 1;
+  const float zlo = qz - r, zhi = qz + r;
+  if (isfinite(r) && zlo > 1.0f) {                       // otherwise the whole crop (valid points have 0 < Z <= 900)
+    const float ilo = __builtin_amdgcn_rcpf(zlo), ihi = __builtin_amdgcn_rcpf(zhi);
+    const float xlo = qx - r, xhi = qx + r, ylo = qy - r, yhi = qy + r;
+    const int iul = cvt_i32_sat(ceilf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - cul));
+    const int iuh = cvt_i32_sat(floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - cuh));
+    const int ivl = cvt_i32_sat(ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - cvl));
+    const int ivh = cvt_i32_sat(floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - cvh));
+    u_lo = max(iul, 0);
+    u_hi = min(iuh, g.cw - 1);
+    v_lo = max(ivl, 0);
+    v_hi = min(ivh, g.ch - 1);
+  }
+  return u_lo <= u_hi && v_lo <= v_hi;
 }
 
 // every lane's window enumerated in lockstep, maxh rows of maxw positions, FL_ICP_NBQ positions per batch (lanes with a
@@ -978,6 +1035,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     S.px = 0.f;
 #ifdef FL_ICP_PHASES
     for (int i = 0; i < 16; ++i) S.tacc[i] = 0;
+    for (int i = 0; i < 40; ++i) S.hist[i] = 0;
     S.tlast = clock64();
     S.tacc[6] = S.tlast - S.tkernel;
 #endif
@@ -1141,6 +1199,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           atomicAdd((unsigned long long *)&S.tacc[10], wc.staged ? 0ull : 1ull);
           atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)wc.area);
           if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(wc.maxw * wc.maxh));
+          const int wcl = wc.W <= 13 ? 0 : (wc.W <= 29 ? 1 : (wc.W <= 61 ? 2 : 3)), hcl = wc.H <= 5 ? 0 : (wc.H <= 10 ? 1 : (wc.H <= 20 ? 2 : 3));
+          atomicAdd(&S.hist[wcl * 4 + hcl], 1u);
+          atomicAdd(&S.hist[16 + min(wc.maxh, 10) - 1], 1u);
+          atomicAdd(&S.hist[26 + (wc.maxw <= 4 ? 0 : (wc.maxw <= 8 ? 1 : (wc.maxw <= 12 ? 2 : 3)))], 1u);
         }
 #endif
         unsigned long long best;
@@ -1158,6 +1220,158 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
     }
   };
+  // FL_ICP_SEARCH 2 -- the same search with less work around the distance scan of a step (the scan itself is unchanged):
+  //  * the union rectangle is staged in whole passes of 64 points, as many as it needs (a compile-time count per case), the
+  //    point of a slot by a reciprocal multiply: no division, no per-pass predicate, no separate guard points (measured:
+  //    rows padded to 16 / 32 / 64 points need no address arithmetic at all, but nine steps in ten are 14 - 29 pixels wide
+  //    and would stage twice the points: 26.8 against 25.4 ms per 2560 frames, profiles/README.md);
+  //  * the five wave reductions (union rectangle, tallest lane window) are interleaved (wave_max_multi), the batches per
+  //    row come from two ballots;
+  //  * the window arithmetic has its constants folded and leaves the clamping to the saturating float -> int conversion.
+  auto org_search2 = [&](const float r_lim, const bool poll_stop, auto &&found) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    static_assert(sizeof(S.prod) + sizeof(S.dtile) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
+    static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
+    float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
+    const float4 *refimg = sref;
+    const int last_s = n_model - 1;
+    const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
+    constexpr int stride = NW * 64;
+    int static_next = wv * 64 + 4 * stride;
+    auto claim = [&](int count) {                          // `count` queries off the workgroup's list (wave-uniform result)
+      int v = 0;
+      if (lane == 0) v = atomicAdd(&S.a1_next, count);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto next_step = [&]() {
+      if (SPEC) return claim(64);
+      const int v = static_next;
+      static_next += stride;
+      return v;
+    };
+    const int sdist = SPEC ? 64 : stride;
+    int sb0 = SPEC ? claim(256) : wv * 64, sb1 = sb0 + sdist, sb2 = sb0 + 2 * sdist, sb3 = sb0 + 3 * sdist;
+    int i_c = ld_u32(perm, min(sb0 + lane, last_s));
+    int i_n = ld_u32(perm, min(sb1 + lane, last_s));
+    int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
+    F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
+    float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
+    while (sb0 < n_model) {
+      if (poll_stop && *(volatile int *)&S.stop) break;
+      const int sb4 = next_step();
+      const int i = i_c;
+      const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
+      const bool active = sb0 + lane < n_model;
+      const bool queryable = active && r_lim >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
+      // ---- this lane's window, the union rectangle, the tallest window ----
+      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
+      bool some = false;
+      if (queryable) some = org_window2(og, cul, cuh, cvl, cvh, qx, qy, qz, nn_radius(qx, qy, qz, fminf(b_c, r_lim)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_lim
+      const int big = 0x3fffffff;
+      int red[5] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0};
+      wave_max_multi(red);
+      const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3], maxh = red[4];
+      const bool any = U1 >= U0;                            // wave-uniform: some lane has a window
+      // the loads of the step after next (the next one's are in flight)
+      const F3 q_nn = ld3_u32(mod, i_nn);
+      const float b_nn = ld_u32(bnd, i_nn);
+      const int i_nnn = ld_u32(perm, min(sb3 + lane, last_s));
+      int j = -1;
+      float d = NAN;
+      if (any) {
+        if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one point of the union: a real
+                                                             // reference point beyond their radius, which the gate drops
+        const int wl = u_hi - u_lo, hl = v_hi - v_lo;
+        // 4-wide batches per row of the widest lane window: 1 or 2 by ballot, beyond that by a reduction (first iterations)
+        int nbw = 1;
+        if (__ballot(wl > 3) != 0ull) nbw = __ballot(wl > 7) == 0ull ? 2 : (wave_max_i(wl) >> 2) + 1;
+        const int W = U1 - U0 + 1, H = V1 - V0 + 1, area = W * H;
+        // The union rectangle is staged row by row at its own width: LDS slot k = lane + 64 p holds its point (k / W, k % W).
+        // Whole passes of 64 slots are staged, enough for the rectangle and the 3 slots a 4-wide batch may run past its last
+        // row; slots past the rectangle hold further points of the image (or the points at infinity behind it), which is
+        // all a scan may ever look at: a real reference point of this frame or infinity never changes the nearest one.
+        const int npneed = (area + 3 + 63) >> 6, npass = npneed <= 2 ? 2 : (npneed <= 4 ? npneed : 6);
+        const bool staged = npneed <= 6;
+#ifdef FL_ICP_PHASES
+        if (lane == 0) {
+          atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
+          atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(4 * nbw * maxh));
+          atomicAdd((unsigned long long *)&S.tacc[10], staged ? 0ull : 1ull);
+          atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)(staged ? npass * 64 : 0));
+          if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(4 * nbw * maxh));
+          const int wcl = W <= 13 ? 0 : (W <= 29 ? 1 : (W <= 61 ? 2 : 3)), hcl = H <= 5 ? 0 : (H <= 10 ? 1 : (H <= 20 ? 2 : 3));
+          atomicAdd(&S.hist[wcl * 4 + hcl], 1u);
+          atomicAdd(&S.hist[16 + min(maxh, 10) - 1], 1u);
+          atomicAdd(&S.hist[26 + min(nbw, 4) - 1], 1u);
+        }
+#endif
+        unsigned long long best = NN_KEY_NONE;
+        if (staged) {
+          // k / W by reciprocal: (k + 0.5) / W stays 0.5 / W away from the integers, three orders of magnitude more than the
+          // error of v_rcp_f32 and the product (k < 448)
+          const float invW = uniform_f(__builtin_amdgcn_rcpf((float)W));
+          const int base = (int)__umul24((unsigned)V0, (unsigned)og.cw) + U0, last_pt = og.cw * og.ch + NN_OVERRUN - 1;
+          auto stage_passes = [&](auto np_) {
+            constexpr int NP = decltype(np_)::value;
+            float4 R[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+              const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
+              R[p] = ld_u32(refimg, min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt));
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) stage[lane + 64 * p] = R[p];
+          };
+          if (npass == 3) stage_passes(std::integral_constant<int, 3>());
+          else if (npass == 4) stage_passes(std::integral_constant<int, 4>());
+          else if (npass == 2) stage_passes(std::integral_constant<int, 2>());
+          else stage_passes(std::integral_constant<int, 6>());
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // scan: maxh rows (a lane with fewer re-reads its last one) of nbw batches of 4 consecutive points (a window narrower
+          // than 4 reads on into the next points of its row, of the next row, or of the slots behind the rectangle)
+          const float4 *row0 = stage + (v_lo - V0) * W + (u_lo - U0);
+          if (nbw == 1) {                                      // every lane's window is at most 4 wide: one batch per row
+            for (int dv = 0; dv < maxh; ++dv) {
+              const float4 *bp = row0 + min(dv, hl) * W;
+              float4 cur[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) cur[e] = bp[e];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+            }
+          } else {
+            const int wlc = max(wl - 3, 0);
+            for (int dv = 0; dv < maxh; ++dv) {
+              const float4 *rowp = row0 + min(dv, hl) * W;
+              for (int du = 0; du < 4 * nbw; du += 4) {
+                const float4 *bp = rowp + min(du, wlc);
+                float4 cur[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur[e] = bp[e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+              }
+            }
+          }
+        } else {
+          best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, 4 * nbw, maxh);
+        }
+        if (queryable) NN_UNPACK(best, &j, &d)
+      }
+      found(active, i, qx, qy, qz, j, d);
+      i_c = i_n; q_c = q_n; b_c = b_n;
+      i_n = i_nn; q_n = q_nn; b_n = b_nn;
+      i_nn = i_nnn;
+      sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
+    }
+  };
+#if FL_ICP_SEARCH == 2
+#define ORG_SEARCH org_search2
+#else
+#define ORG_SEARCH org_search
+#endif
   // the deferred dist_mean chain of the pending distances (chain wave), then -- every wave -- the search for the next iteration
   auto chain_and_search = [&](const int pend, const bool want, const float r_lim, const float old_mean_) {
     if (pend && threadIdx.x < 64) {
@@ -1181,7 +1395,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       }
     }
     if (want)
-      org_search(r_lim, true, [&](bool active, int i, float, float, float, int j, float d) {
+      ORG_SEARCH(r_lim, true, [&](bool active, int i, float, float, float, int j, float d) {
         if (active) {
           nn[i] = j;
           nd[i] = d;
@@ -1259,7 +1473,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
         if (!SPEC)
-          org_search(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
+          ORG_SEARCH(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
             const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
             if (active) {
               nn[i] = keep ? j : -1;
@@ -1899,6 +2113,12 @@ void k_icp_pipeline(IcpArgs a)
     res->pose[12] = res->pose[13] = res->pose[14] = 0.f;
     res->pose[15] = 1.f;
     res->found = 1;
+#ifdef FL_ICP_PHASES
+    // dev build only: histograms of the organised search instead of the pose
+    for (int i = 0; i < 16; ++i) res->pose[i] = (float)S.hist[i];
+    for (int i = 0; i < 9; ++i) res->det.R_final[i] = (float)S.hist[16 + i];
+    for (int i = 0; i < 3; ++i) res->det.T_final[i] = (float)S.hist[26 + i];
+#endif
   }
 }
 
