@@ -401,6 +401,10 @@ def main():
               "staged points per step %.0f" % (st[0], st[1] / max(st[0], 1), 100 * st[4] / max(st[1], 1), 100 * st[2] / max(st[0], 1),
                                                 st[3] / max(st[0], 1)), file=sys.stderr)
         hs = np.array([list(r.pose) + list(r.det.R_final) + list(r.det.T_final) for r in res]).sum(0)
+        stt = hs[11:16].copy() / len(res) / 4e6              # per wave (4 waves per workgroup), M cycles
+        hs[11:16] = 0
+        print("icp search step segments, M cycles per wave: wait for the query %.2f, window + reductions %.2f, staging %.2f, scan %.2f, "
+              "epilogue + stores %.2f" % tuple(stt), file=sys.stderr)
         tot = max(hs[:16].sum(), 1)
         print("icp union classes %% of steps, rows W<=13,<=29,<=61,>61 x cols H<=5,<=10,<=20,>20: %s | largest lane window height 1..9+: %s | "
               "width <=4,<=8,<=12: %s" % (np.round(100 * hs[:16].reshape(4, 4) / tot, 1).tolist(), np.round(100 * hs[16:25] / tot, 1).tolist(),

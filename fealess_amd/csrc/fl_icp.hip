@@ -97,9 +97,10 @@
                                   // (1: in the 1024-thread kernel, 2: in both, 0: off)
 #endif
 #ifndef FL_ICP_SEARCH
-#define FL_ICP_SEARCH 2           // organised search, the step's overhead around the distance scan: 1 = round 2 (union window staged at its
+#define FL_ICP_SEARCH 3           // organised search, the step's overhead around the distance scan: 1 = round 2 (union window staged at its
                                   // own width, six serial wave reductions), 2 = staged rows of 16 / 32 / 64 points (no address arithmetic
-                                  // per staged point), five interleaved reductions, batches per row by ballot
+                                  // per staged point), five interleaved reductions, batches per row by ballot; 3 = 2 software-pipelined
+                                  // over its steps (the next step's rectangle fetched by LDS-DMA while this one is scanned), 256-thread kernels
 #endif
 #define ICP_STAGE_CAP 384         // points a wave stages per search step (FL_ICP_SEARCH 2): six passes of 64
 #ifndef FL_ICP_NB
@@ -223,6 +224,7 @@ struct IcpSharedT {
   alignas(16) float dchain[2][ICP_DT];   // the deferred dist_mean chain's staging (chain wave only)
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
+  unsigned long long stime[8];         // FL_ICP_PHASES: cycles of the search step's segments, summed over the workgroup's waves
   unsigned hist[40];                    // organised search: [0,16) union (W class x H class), [16,26) largest lane window height, [26,30) width class
 #endif
 };
@@ -474,6 +476,37 @@ __device__ __forceinline__ T ld_u32(const T *__restrict__ base, int idx)
 {
   return *(const T *)((const char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
 }
+
+// Vector-memory operations as inline assembly: the compiler's s_waitcnt bookkeeping does not see them (the pipelined
+// organised search counts their completion itself, see FL_ICP_SEARCH 3).  A load's destination is valid only after the
+// s_waitcnt that retires it; nothing may read or copy it before.
+typedef float f3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void asm_ld_i32(int &dst, const int *base, int idx)
+{
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"((unsigned)idx * 4u), "s"(base) : "memory");
+}
+__device__ __forceinline__ void asm_ld_f32(float &dst, const float *base, int idx)
+{
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"((unsigned)idx * 4u), "s"(base) : "memory");
+}
+__device__ __forceinline__ void asm_ld_f3(f3v &dst, const float *base, int idx)
+{
+  asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(dst) : "v"((unsigned)idx * 12u), "s"(base) : "memory");
+}
+struct StorePlain {                                      // st(base, i, v): base[i] = v
+  __device__ __forceinline__ void operator()(int *base, int i, int v) const { base[i] = v; }
+  __device__ __forceinline__ void operator()(float *base, int i, float v) const { base[i] = v; }
+};
+struct StoreAsm {
+  __device__ __forceinline__ void operator()(int *base, int i, int v) const
+  {
+    asm volatile("global_store_dword %0, %1, %2" : : "v"((unsigned)i * 4u), "v"(v), "s"(base) : "memory");
+  }
+  __device__ __forceinline__ void operator()(float *base, int i, float v) const
+  {
+    asm volatile("global_store_dword %0, %1, %2" : : "v"((unsigned)i * 4u), "v"(v), "s"(base) : "memory");
+  }
+};
 
 // one 12-byte load (global_load_dwordx3) for a point instead of three dword loads: the phases are bound by the
 // number of vector-memory instructions as much as by anything else
@@ -1036,6 +1069,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 #ifdef FL_ICP_PHASES
     for (int i = 0; i < 16; ++i) S.tacc[i] = 0;
     for (int i = 0; i < 40; ++i) S.hist[i] = 0;
+    for (int i = 0; i < 8; ++i) S.stime[i] = 0;
     S.tlast = clock64();
     S.tacc[6] = S.tlast - S.tkernel;
 #endif
@@ -1213,7 +1247,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
                           wc.maxh);
         if (queryable) NN_UNPACK(best, &j, &d)
       }
-      found(active, i, qx, qy, qz, j, d);
+      found(active, i, qx, qy, qz, j, d, StorePlain());
       i_c = i_n; q_c = q_n; b_c = b_n;
       i_n = i_nn; q_n = q_nn; b_n = b_nn;
       i_nn = i_nnn;
@@ -1256,11 +1290,21 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
     F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
     float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
+#ifdef FL_ICP_PHASES
+    long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = clock64();
+#define ST_STAMP(k) { const long long now_ = clock64(); st_acc[k] += now_ - st_last; st_last = now_; }
+#else
+#define ST_STAMP(k) { }
+#endif
     while (sb0 < n_model) {
       if (poll_stop && *(volatile int *)&S.stop) break;
       const int sb4 = next_step();
       const int i = i_c;
       const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
+#ifdef FL_ICP_PHASES
+      asm volatile("" :: "v"(qx), "v"(b_c));             // the query and its bound have arrived
+#endif
+      ST_STAMP(0)
       const bool active = sb0 + lane < n_model;
       const bool queryable = active && r_lim >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
       // ---- this lane's window, the union rectangle, the tallest window ----
@@ -1272,6 +1316,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       wave_max_multi(red);
       const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3], maxh = red[4];
       const bool any = U1 >= U0;                            // wave-uniform: some lane has a window
+      ST_STAMP(1)
       // the loads of the step after next (the next one's are in flight)
       const F3 q_nn = ld3_u32(mod, i_nn);
       const float b_nn = ld_u32(bnd, i_nn);
@@ -1329,6 +1374,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          ST_STAMP(2)
           // scan: maxh rows (a lane with fewer re-reads its last one) of nbw batches of 4 consecutive points (a window narrower
           // than 4 reads on into the next points of its row, of the next row, or of the slots behind the rectangle)
           const float4 *row0 = stage + (v_lo - V0) * W + (u_lo - U0);
@@ -1359,19 +1405,236 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, 4 * nbw, maxh);
         }
         if (queryable) NN_UNPACK(best, &j, &d)
+#ifdef FL_ICP_PHASES
+        asm volatile("" :: "v"(j), "v"(d));
+#endif
+        ST_STAMP(3)
       }
-      found(active, i, qx, qy, qz, j, d);
+      found(active, i, qx, qy, qz, j, d, StorePlain());
       i_c = i_n; q_c = q_n; b_c = b_n;
       i_n = i_nn; q_n = q_nn; b_n = b_nn;
       i_nn = i_nnn;
       sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
+      ST_STAMP(4)
     }
-  };
-#if FL_ICP_SEARCH == 2
-#define ORG_SEARCH org_search2
-#else
-#define ORG_SEARCH org_search
+#ifdef FL_ICP_PHASES
+    if (lane == 0)
+      for (int k = 0; k < 5; ++k) atomicAdd(&S.stime[k], (unsigned long long)st_acc[k]);
 #endif
+#undef ST_STAMP
+  };
+  // FL_ICP_SEARCH 3 -- the same search, software-pipelined over its steps.  The stamps of a step (profiles/README.md) show
+  // what a wave waits for: the staging loads' round trip (47 % of the phase: the reference images of a few thousand frames
+  // live in HBM) and, at the loop's head, the stores and prefetches of the step before (20 %: vmcnt counts loads and stores
+  // in one in-order queue); window arithmetic and reductions are 6 %, the scan 24 %.  So the union rectangle of step k + 1 is
+  // fetched while step k is scanned: window, reductions and rectangle of the NEXT step are computed first, its points go
+  // from the image straight into the wave's other LDS buffer by LDS-DMA (global_load_lds_dwordx4: no destination
+  // registers, no ds_write), and the wait for them sits at the head of the next step, one whole scan later.  A step's
+  // results are stored at the head of the step after it, in front of that step's transfers.  Every vector-memory operation
+  // of the loop's common path is inline assembly on purpose: the compiler's s_waitcnt bookkeeping does not see them, so it
+  // neither waits for the transfers in front of the scan's ds_reads nor turns its own counted waits into waits for
+  // operations it cannot count; their completion is counted here: ONE s_waitcnt vmcnt(0) per step, at its head, for
+  // operations that were issued a whole scan earlier.  A rectangle of more than three passes of 64 points, or the step
+  // after one (it occupies both buffers), is staged the synchronous way of FL_ICP_SEARCH 2.
+  auto org_search3 = [&](const float r_lim, const bool poll_stop, auto &&found) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    static_assert(sizeof(S.prod) + sizeof(S.dtile) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
+    static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
+    constexpr int DP = ICP_STAGE_CAP / 128;                // passes of 64 points per LDS buffer; a wave's region is two buffers
+    float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
+    const unsigned stage_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)stage);   // LDS byte address (flat aperture: low word)
+    const float4 *refimg = sref;
+    const int last_s = n_model - 1, last_pt = og.cw * og.ch + NN_OVERRUN - 1;
+    const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
+    constexpr int stride = NW * 64;
+    int static_next = wv * 64 + 4 * stride;
+    auto claim = [&](int count) {                          // `count` queries off the workgroup's list (wave-uniform result)
+      int v = 0;
+      if (lane == 0) v = atomicAdd(&S.a1_next, count);
+      return __builtin_amdgcn_readfirstlane(v);
+    };
+    auto next_step = [&]() {
+      if (SPEC) return claim(64);
+      const int v = static_next;
+      static_next += stride;
+      return v;
+    };
+    struct Prep {                                          // a step whose window arithmetic is done
+      int u_lo, u_hi, v_lo, v_hi;                          // this lane's window (a lane without one looks at (U0, V0))
+      int U0, V0, W, maxh, nbw, npneed;                    // wave-uniform: union rectangle, tallest window, batches per row, passes
+      bool any;                                            // wave-uniform: some lane has a window
+    };
+    auto prepare = [&](float qx, float qy, float qz, float b, bool queryable, Prep &w) {
+      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
+      bool some = false;
+      if (queryable) some = org_window2(og, cul, cuh, cvl, cvh, qx, qy, qz, nn_radius(qx, qy, qz, fminf(b, r_lim)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_lim
+      const int big = 0x3fffffff;
+      int red[5] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0};
+      wave_max_multi(red);
+      const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3];
+      w.any = U1 >= U0;
+      w.U0 = U0; w.V0 = V0; w.W = 1; w.maxh = red[4]; w.nbw = 1; w.npneed = 0;
+      if (w.any) {
+        if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one point of the union: a real
+                                                             // reference point beyond their radius, which the gate drops
+        const int wl = u_hi - u_lo;
+        // 4-wide batches per row of the widest lane window: 1 or 2 by ballot, beyond that by a reduction (first iterations)
+        if (__ballot(wl > 3) != 0ull) w.nbw = __ballot(wl > 7) == 0ull ? 2 : (wave_max_i(wl) >> 2) + 1;
+        w.W = U1 - U0 + 1;
+        w.npneed = (w.W * (V1 - V0 + 1) + 3 + 63) >> 6;     // passes of 64 slots: the rectangle + the 3 slots a batch may overrun it by
+      }
+      w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
+    };
+    // image index of staged slot k = lane + 64 p of the rectangle (see FL_ICP_SEARCH 2)
+    auto slot_index = [&](const Prep &w, float invW, int base, int p) {
+      const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * w.W;
+      return min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
+    };
+    auto issue_dma = [&](const Prep &w, int buf) {         // up to DP passes into buffer `buf`, not waited for
+      const float invW = uniform_f(__builtin_amdgcn_rcpf((float)w.W));
+      const int base = (int)__umul24((unsigned)w.V0, (unsigned)og.cw) + w.U0;
+#pragma unroll
+      for (int p = 0; p < DP; ++p) {
+        if (p < w.npneed) {
+          const float4 *src = refimg + (unsigned)slot_index(w, invW, base, p);
+          const unsigned dst = stage_lds + (unsigned)(buf * DP + p) * 1024u;
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+      }
+    };
+    auto stage_sync = [&](const Prep &w, float4 *dst) {    // the synchronous way: registers, ds_write, wait
+      const float invW = uniform_f(__builtin_amdgcn_rcpf((float)w.W));
+      const int base = (int)__umul24((unsigned)w.V0, (unsigned)og.cw) + w.U0;
+      auto passes = [&](auto np_) {
+        constexpr int NP = decltype(np_)::value;
+        float4 R[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) R[p] = ld_u32(refimg, slot_index(w, invW, base, p));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) dst[lane + 64 * p] = R[p];
+      };
+      if (w.npneed <= 2) passes(std::integral_constant<int, 2>());
+      else if (w.npneed == 3) passes(std::integral_constant<int, 3>());
+      else if (w.npneed == 4) passes(std::integral_constant<int, 4>());
+      else passes(std::integral_constant<int, 6>());
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto scan_staged = [&](const Prep &w, const float4 *buf, float qx, float qy, float qz) {
+      unsigned long long best = NN_KEY_NONE;
+      const int wl = w.u_hi - w.u_lo, hl = w.v_hi - w.v_lo;
+      const float4 *row0 = buf + (w.v_lo - w.V0) * w.W + (w.u_lo - w.U0);
+      if (w.nbw == 1) {                                    // every lane's window is at most 4 wide: one batch per row
+        for (int dv = 0; dv < w.maxh; ++dv) {
+          const float4 *bp = row0 + min(dv, hl) * w.W;
+          float4 cur[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cur[e] = bp[e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+        }
+      } else {
+        const int wlc = max(wl - 3, 0);
+        for (int dv = 0; dv < w.maxh; ++dv) {
+          const float4 *rowp = row0 + min(dv, hl) * w.W;
+          for (int du = 0; du < 4 * w.nbw; du += 4) {
+            const float4 *bp = rowp + min(du, wlc);
+            float4 cur[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[e] = bp[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+          }
+        }
+      }
+      return best;
+    };
+    const int sdist = SPEC ? 64 : stride;
+    int sb0 = SPEC ? claim(256) : wv * 64, sb1 = sb0 + sdist, sb2 = sb0 + 2 * sdist, sb3 = sb0 + 3 * sdist;
+    auto queryable_at = [&](int sb, float qx, float qy, float qz) { return sb + lane < n_model && r_lim >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz); };
+    // Register pipeline of the queries: the index of step k + 3 and the point and bound of step k + 2 are loaded during step
+    // k into in_i / in_q / in_b, which nothing reads before the s_waitcnt at the head of step k + 1; only there are they
+    // rotated into the registers the next steps compute with.
+    int i_c = 0, i_n, i_nn, in_i;
+    float qcx = 0.f, qcy = 0.f, qcz = 0.f, qnx, qny, qnz, b_n, in_b;
+    f3v in_q;
+    {
+      const int i0 = ld_u32(perm, min(sb0 + lane, last_s)), i1 = ld_u32(perm, min(sb1 + lane, last_s));
+      in_i = ld_u32(perm, min(sb2 + lane, last_s));
+      const F3 q0 = ld3_u32(mod, i0), q1 = ld3_u32(mod, i1);
+      i_n = i0; qnx = q0.x; qny = q0.y; qnz = q0.z; b_n = ld_u32(bnd, i0);
+      i_nn = i1; in_q.x = q1.x; in_q.y = q1.y; in_q.z = q1.z; in_b = ld_u32(bnd, i1);
+    }
+    bool pend = false, p_active = false;                   // the previous step's result, not yet handed to found()
+    int p_i = 0, p_j = -1;
+    float p_qx = 0.f, p_qy = 0.f, p_qz = 0.f, p_d = NAN;
+    Prep cur, nxt;
+    bool nxt_pre = false;                                  // the next step's rectangle is being fetched into its buffer by LDS-DMA
+    int nxt_buf = 0;
+    nxt.any = false; nxt.npneed = 0; nxt.u_lo = nxt.u_hi = nxt.v_lo = nxt.v_hi = 0; nxt.U0 = nxt.V0 = 0; nxt.W = 1; nxt.maxh = 0; nxt.nbw = 1;
+    if (sb0 < n_model) prepare(qnx, qny, qnz, b_n, queryable_at(sb0, qnx, qny, qnz), nxt);
+    while (sb0 < n_model) {
+      if (poll_stop && *(volatile int *)&S.stop) break;
+      const int sb4 = next_step();
+      // everything the step before issued has landed: this step's rectangle (LDS-DMA), the queries of the next two steps
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_q), "+v"(in_b), "+v"(in_i) : : "memory");
+      __builtin_amdgcn_wave_barrier();
+      cur = nxt;
+      const bool cur_pre = nxt_pre;
+      const int cur_buf = nxt_buf;
+      i_c = i_n; qcx = qnx; qcy = qny; qcz = qnz;
+      i_n = i_nn; qnx = in_q.x; qny = in_q.y; qnz = in_q.z; b_n = in_b;
+      i_nn = in_i;
+      // the loads of the steps after next, then the results of the step before, then the next step's rectangle
+      asm_ld_f3(in_q, mod, i_nn);
+      asm_ld_f32(in_b, bnd, i_nn);
+      asm_ld_i32(in_i, perm, min(sb3 + lane, last_s));
+      if (pend) { found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d, StoreAsm()); pend = false; }
+      nxt.any = false; nxt.npneed = 0;
+      nxt_pre = false;
+      nxt_buf = cur_buf ^ 1;
+      if (sb1 < n_model) {
+        prepare(qnx, qny, qnz, b_n, queryable_at(sb1, qnx, qny, qnz), nxt);
+        if (nxt.any && nxt.npneed <= DP && (!cur.any || cur.npneed <= DP)) {   // fits one buffer, and this step leaves that buffer alone
+          issue_dma(nxt, nxt_buf);
+          nxt_pre = true;
+        }
+      }
+      // this step
+      const bool active = sb0 + lane < n_model;
+      int j = -1;
+      float d = NAN;
+      if (cur.any) {
+        unsigned long long best;
+        if (cur_pre) {
+          best = scan_staged(cur, stage + cur_buf * (DP * 64), qcx, qcy, qcz);
+        } else if (cur.npneed <= 2 * DP) {
+          float4 *dst = stage + (cur.npneed <= DP ? cur_buf * (DP * 64) : 0);
+          stage_sync(cur, dst);
+          best = scan_staged(cur, dst, qcx, qcy, qcz);
+        } else {
+          best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qcx, qcy, qcz, cur.u_lo, cur.u_hi, cur.v_lo, cur.v_hi, 4 * cur.nbw, cur.maxh);
+        }
+        if (queryable_at(sb0, qcx, qcy, qcz)) NN_UNPACK(best, &j, &d)
+      }
+      pend = true; p_active = active; p_i = i_c; p_qx = qcx; p_qy = qcy; p_qz = qcz; p_j = j; p_d = d;
+      sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_q), "+v"(in_b), "+v"(in_i) : : "memory");   // transfers and loads in flight (poll_stop, or past the end)
+    if (pend) found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d, StoreAsm());
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores: the barrier that follows does not know about them
+  };
+  // which search: the pipelined one only in the 256-thread kernels (the LDS addresses of the 1024-thread kernel's staging
+  // region lie beyond the 64 KB an M0 base was checked with)
+  auto org_search_pick = [&](const float r_lim, const bool poll_stop, auto &&found) {
+    if constexpr (FL_ICP_SEARCH == 3 && BS == ICP_BS_SMALL) org_search3(r_lim, poll_stop, found);
+    else if constexpr (FL_ICP_SEARCH >= 2) org_search2(r_lim, poll_stop, found);
+    else org_search(r_lim, poll_stop, found);
+  };
+#define ORG_SEARCH org_search_pick
   // the deferred dist_mean chain of the pending distances (chain wave), then -- every wave -- the search for the next iteration
   auto chain_and_search = [&](const int pend, const bool want, const float r_lim, const float old_mean_) {
     if (pend && threadIdx.x < 64) {
@@ -1395,11 +1658,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       }
     }
     if (want)
-      ORG_SEARCH(r_lim, true, [&](bool active, int i, float, float, float, int j, float d) {
+      ORG_SEARCH(r_lim, true, [&](bool active, int i, float, float, float, int j, float d, auto &&st) {
         if (active) {
-          nn[i] = j;
-          nd[i] = d;
-          if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
+          st(nn, i, j);
+          st(nd, i, d);
+          if (j >= 0) st(bnd, i, sqrt_upper(d));          // else: the old partner is still within the old bound
         }
       });
   };
@@ -1473,11 +1736,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
         if (!SPEC)
-          ORG_SEARCH(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
+          ORG_SEARCH(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d, auto &&st) {
             const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
             if (active) {
-              nn[i] = keep ? j : -1;
-              if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
+              st(nn, i, keep ? j : -1);
+              if (j >= 0) st(bnd, i, sqrt_upper(d));          // else: the old partner is still within the old bound
             }
             if (keep) {
               ++kept;
@@ -2118,6 +2381,7 @@ void k_icp_pipeline(IcpArgs a)
     for (int i = 0; i < 16; ++i) res->pose[i] = (float)S.hist[i];
     for (int i = 0; i < 9; ++i) res->det.R_final[i] = (float)S.hist[16 + i];
     for (int i = 0; i < 3; ++i) res->det.T_final[i] = (float)S.hist[26 + i];
+    for (int i = 0; i < 5; ++i) res->pose[11 + i] = (float)S.stime[i];   // the last five union classes (wider than 29 pixels) make room
 #endif
   }
 }
