@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--templates", type=int, default=2000)
     ap.add_argument("--levels", type=int, default=0, help="pyramid levels (default: 2 for c2, 3 for c3)")
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per step per GPU (default 2560 for c2 = two rounds of 5 ICP workgroups on each of the 256 CUs; 256 for c3)")
+                    help="frames per step per GPU (default 4096 for c2 = four rounds of 4 ICP workgroups on each of the 256 CUs; 256 for c3)")
     ap.add_argument("--icp-iters", type=int, default=20)
     ap.add_argument("--icp-mode", choices=["parity", "fast", "plane"], default="parity")
     ap.add_argument("--scenes", type=int, default=16)
@@ -85,7 +85,7 @@ def parse():
     if a.levels == 0:
         a.levels = 3 if a.config == "c3" else 2
     if a.batch == 0:
-        a.batch = 256 if a.config == "c3" else 2560
+        a.batch = 256 if a.config == "c3" else 4096
     return a
 
 
@@ -400,9 +400,21 @@ def main():
         print("icp organised search per frame: steps %.0f, positions per step %.1f (iterations 1-3: %.0f%% of all), fallback steps %.1f%%, "
               "staged points per step %.0f" % (st[0], st[1] / max(st[0], 1), 100 * st[4] / max(st[1], 1), 100 * st[2] / max(st[0], 1),
                                                 st[3] / max(st[0], 1)), file=sys.stderr)
-        hs = np.array([list(r.pose) + list(r.det.R_final) + list(r.det.T_final) for r in res]).sum(0)
+        pw = np.array([list(r.pose)[:5] for r in res], np.float64)
+        t0 = (pw[:, 0] * 2 ** 24 + pw[:, 1]) / 100.0            # us
+        t1 = (pw[:, 2] * 2 ** 24 + pw[:, 3]) / 100.0
+        span = t1.max() - t0.min()
+        life = t1 - t0
+        print("icp workgroup timeline (100 MHz wall clock): launch span %.0f us, workgroup lifetime mean %.0f us (min %.0f, max %.0f), "
+              "sum of lifetimes / (span x %d slots) = %.3f; last start %.0f us, first end %.0f us, workgroups ending in the last 10 %% of the span: %d" %
+              (span, life.mean(), life.min(), life.max(), min(len(res), 1280), life.sum() / (span * min(len(res), 1280)), t0.max() - t0.min(),
+               t1.min() - t0.min(), int((t1 > t0.min() + 0.9 * span).sum())), file=sys.stderr)
+        hs = np.array([[0.0] * 5 + list(r.pose)[5:] + list(r.det.R_final) + list(r.det.T_final) for r in res]).sum(0)
         stt = hs[11:16].copy() / len(res) / 4e6              # per wave (4 waves per workgroup), M cycles
         hs[11:16] = 0
+        a2 = hs[22:25].copy() / len(res) / 1e6
+        hs[22:25] = 0
+        print("icp phase A2, M cycles per workgroup: chain wave adding %.2f, chain wave at the tile barrier %.2f, a producer wave at the tile barrier %.2f" % tuple(a2), file=sys.stderr)
         print("icp search step segments, M cycles per wave: wait for the query %.2f, window + reductions %.2f, staging %.2f, scan %.2f, "
               "epilogue + stores %.2f" % tuple(stt), file=sys.stderr)
         tot = max(hs[:16].sum(), 1)
@@ -581,7 +593,7 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
     BASELINE configs[1] and the data-independent eager front-end -- each a short run of its own."""
     out = {}
     sweep = []
-    for b in (1, 8, 64, 256, 1024, 2048, 2560):
+    for b in (1, 8, 64, 256, 1024, 2048, 2560, 4096):
         if b > args.batch:
             continue
         el1 = run.timed(1, 1, n=b)

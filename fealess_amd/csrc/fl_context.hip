@@ -176,6 +176,7 @@ static void free_device_tables(fl_detector *det)
   for (auto &e : det->ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (det->d_jobs) { (void)hipFree(det->d_jobs); det->d_jobs = nullptr; }
+  if (det->d_icp_order) { (void)hipFree(det->d_icp_order); det->d_icp_order = nullptr; }
   det->selected_frames = 0;
   if (det->d_zoom) { (void)hipFree(det->d_zoom); det->d_zoom = nullptr; }
   if (det->d_zoom_src) { (void)hipFree(det->d_zoom_src); det->d_zoom_src = nullptr; det->zoom_src_bytes = 0; }

@@ -180,6 +180,7 @@ struct IcpArgs {
   const uint16_t *const *depth_ptrs;
   fl_recognition_result *results;
   const FlRefineJob *jobs;     // kind 0 with caller-chosen matches (fl_refine_matches): job b refines jobs[b].match on frame jobs[b].frame
+  const int *order;            // kind 0 batches: workgroup b runs job order[b] (longest first, see k_icp_order); null: job b
 };
 
 // LDS state of one frame workgroup of BS_ threads.  Parity mode: virtual wave 0 chains, the other BS/64 - 1 waves
@@ -224,6 +225,7 @@ struct IcpSharedT {
   alignas(16) float dchain[2][ICP_DT];   // the deferred dist_mean chain's staging (chain wave only)
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
+  long long wall0;                      // wall_clock64() (constant 100 MHz) at kernel entry
   unsigned long long stime[8];         // FL_ICP_PHASES: cycles of the search step's segments, summed over the workgroup's waves
   unsigned hist[40];                    // organised search: [0,16) union (W class x H class), [16,26) largest lane window height, [26,30) width class
 #endif
@@ -919,90 +921,89 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   double dsum[1] = {0.0};
   float acc = 0.0f;
   const int ntiles = (n + TQ - 1) / TQ;
-  // The phase is one memory round trip + one barrier per tile, so the next tile's (coalesced) loads are
-  // issued before this tile is processed: the round trip overlaps the chain of the previous tile.
-  // (PD tiles ahead: with thousands of frames in flight the loads come from HBM, several thousand cycles under load,
-  // while the chain needs a tile every TQ * 8 cycles)
-  constexpr int PD = FL_ICP_PD;
-  float pa[PD][3], pb[PD][3], pbnd[PD];
-#pragma unroll
-  for (int k = 0; k < PD; ++k) { pa[k][0] = pa[k][1] = pa[k][2] = 0.f; pb[k][0] = pb[k][1] = pb[k][2] = 0.f; pbnd[k] = 0.f; }
-  if (slot >= 0) {
-#pragma unroll
-    for (int k = 0; k < PD; ++k) {
-      const int i = min(k * TQ + slot, n - 1);            // clamped: unused past the end
-      { const F3 v3_ = ld3_u32(mod, i); pa[k][0] = v3_.x; pa[k][1] = v3_.y; pa[k][2] = v3_.z; }
-      { const F3 v3_ = ld3_u32(ref, i); pb[k][0] = v3_.x; pb[k][1] = v3_.y; pb[k][2] = v3_.z; }
-      if (Ropt) pbnd[k] = ld_u32(bnd, i);
+  // The phase is one memory round trip + one barrier per tile, so the next tile's (coalesced) loads are issued before this
+  // tile is processed.  Two register sets trade roles by unrolling the tile loop twice -- never by moving registers, and
+  // nothing computes with a loaded value in the iteration that issued its load: either makes the compiler drain the whole
+  // memory queue (s_waitcnt vmcnt(0)) once per tile (see the A2 phase in icp_run).  With chains in this phase (parity) the
+  // tile barrier is a raw s_barrier behind an lgkmcnt wait: the LDS tile must be complete, the global stores of this
+  // phase (mod, bnd) need not be before the phase ends.
+  struct Row { F3 a, b; float bnd; };
+  auto row_load = [&](Row &w, int t) {
+    const int i = min(t * TQ + slot, n - 1);              // clamped: unused past the end
+    w.a = ld3_u32(mod, i);
+    w.b = ld3_u32(ref, i);
+    w.bnd = Ropt ? ld_u32(bnd, i) : 0.0f;
+  };
+  auto row_process = [&](const Row &w, int t) {
+    const int i = t * TQ + slot;
+    float term = 0.0f;
+    float a[3] = {w.a.x, w.a.y, w.a.z};
+    const float b0 = w.b.x, b1 = w.b.y, b2 = w.b.z;
+    if (i < n) {
+      if (Ropt) {
+        float move = 0.0f;
+        if (vvalid(a[2])) {                               // transformPoints in place (:28-45, :756)
+          float o[3];
+          mat_vec(Ropt, a, o);
+          o[0] += Topt[0];
+          o[1] += Topt[1];
+          o[2] += Topt[2];
+          const float mx = o[0] - a[0], my = o[1] - a[1], mz = o[2] - a[2];
+          move = sqrt_upper(mx * mx + my * my + mz * mz);
+          a[0] = o[0];
+          a[1] = o[1];
+          a[2] = o[2];
+          mod[3 * i] = a[0];
+          mod[3 * i + 1] = a[1];
+          mod[3 * i + 2] = a[2];
+        }
+        bnd[i] = w.bnd + move;                            // triangle inequality: still reaches the old partner
+      } else {
+        // first bound: the index pair (n_ref >= n_model); NaN/inf simply disable the bound
+        const float ex = a[0] - b0, ey = a[1] - b1, ez = a[2] - b2;
+        bnd[i] = sqrt_upper(ex * ex + ey * ey + ez * ez);
+      }
+      if (vvalid(b2) && vvalid(a[2])) {
+        const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
+        // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
+        const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+        if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
+        ++counter;
+      }
     }
-  }
+    if (parity) S.dtile[t & 1][slot] = term;              // non-inliers add an exact +0.0f
+    if (DEFER && i < n) dterm[i] = term;
+  };
+  auto tile_barrier = [&]() {
+    if (parity) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);                  // s_waitcnt lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+    }
+  };
   const bool chain_wave = parity && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
-  if (FL_ICP_SPLIT && chain_wave) {
+  if (chain_wave) {
     // the chain wave's own loop (see the A2 phase): one barrier per tile like the producers' below
     for (int t = 0; t < ntiles; ++t) {
       if (t > 0 && threadIdx.x == 0) acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
-      __syncthreads();
+      tile_barrier();
     }
-  } else
-  for (int t = 0; t < ntiles; ++t) {
-    if (slot >= 0) {
-      const int i = t * TQ + slot;
-      float term = 0.0f;
-      float a[3] = {pa[0][0], pa[0][1], pa[0][2]};
-      const float b0 = pb[0][0], b1 = pb[0][1], b2 = pb[0][2];
-      const float bprev = pbnd[0];
-      {
-#pragma unroll
-        for (int k = 0; k + 1 < PD; ++k) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) { pa[k][q] = pa[k + 1][q]; pb[k][q] = pb[k + 1][q]; }
-          pbnd[k] = pbnd[k + 1];
-        }
-        const int in = min(i + PD * TQ, n - 1);           // clamped: unused past the end (this thread owns row i + PD * TQ)
-        { const F3 v3_ = ld3_u32(mod, in); pa[PD - 1][0] = v3_.x; pa[PD - 1][1] = v3_.y; pa[PD - 1][2] = v3_.z; }
-        { const F3 v3_ = ld3_u32(ref, in); pb[PD - 1][0] = v3_.x; pb[PD - 1][1] = v3_.y; pb[PD - 1][2] = v3_.z; }
-        if (Ropt) pbnd[PD - 1] = ld_u32(bnd, in);
+  } else if (slot >= 0) {
+    Row A, B;
+    if (ntiles > 0) row_load(A, 0);
+    for (int t = 0; t < ntiles; t += 2) {
+      row_load(B, t + 1);
+      row_process(A, t);
+      tile_barrier();
+      if (t + 1 < ntiles) {
+        row_load(A, t + 2);
+        row_process(B, t + 1);
+        tile_barrier();
       }
-      if (i < n) {
-        if (Ropt) {
-          float move = 0.0f;
-          if (vvalid(a[2])) {                             // transformPoints in place (:28-45, :756)
-            float o[3];
-            mat_vec(Ropt, a, o);
-            o[0] += Topt[0];
-            o[1] += Topt[1];
-            o[2] += Topt[2];
-            const float mx = o[0] - a[0], my = o[1] - a[1], mz = o[2] - a[2];
-            move = sqrt_upper(mx * mx + my * my + mz * mz);
-            a[0] = o[0];
-            a[1] = o[1];
-            a[2] = o[2];
-            mod[3 * i] = a[0];
-            mod[3 * i + 1] = a[1];
-            mod[3 * i + 2] = a[2];
-          }
-          bnd[i] = bprev + move;                          // triangle inequality: still reaches the old partner
-        } else {
-          // first bound: the index pair (n_ref >= n_model); NaN/inf simply disable the bound
-          const float ex = a[0] - b0, ey = a[1] - b1, ez = a[2] - b2;
-          bnd[i] = sqrt_upper(ex * ex + ey * ey + ez * ez);
-        }
-        if (vvalid(b2) && vvalid(a[2])) {
-          const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
-          // cv::norm(Vec3f): squares accumulated in double, sqrt in double, stored to float (:88)
-          const float dist = (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
-          if (dist <= thr) { term = dist; ++inl; dsum[0] += (double)dist; }
-          ++counter;
-        }
-      }
-      if (parity) S.dtile[t & 1][slot] = term;            // non-inliers add an exact +0.0f
-      if (DEFER && i < n) dterm[i] = term;
-    } else if (!FL_ICP_SPLIT && t > 0 && threadIdx.x == 0) {
-      acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
     }
-    if (parity) __syncthreads();
-
+  } else {
+    for (int t = 0; t < ntiles; ++t) tile_barrier();       // a wave that neither chains nor produces (1024-thread workgroup)
   }
+  __syncthreads();                                         // the phase's stores (mod, bnd, dterm) are visible to the workgroup
   if (parity && ntiles > 0 && threadIdx.x == 0)
     acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
   counter = block_sum_int(S, counter);
@@ -1781,83 +1782,80 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     const int ntiles = (parity || index_pairs) ? (rows + TQ - 1) / TQ : 0;
     float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
     if (parity && iter > 1) {
-      // Register pipeline of the producers: a tile costs nn/mod loads (coalesced) and then the dependent gather ref[j].
-      // With thousands of frames in flight both come from HBM (several thousand cycles under load) while the chain needs a
-      // tile every TQ * 8 cycles, so tile t + PD + 1's loads and the gathers of tiles t + 1 .. t + PD are in flight while
-      // tile t is written.
-      constexpr int PD = FL_ICP_PD;
-      int jq[PD + 1];
-      float mq[PD + 1][3], rq[PD][3];
+      // Register pipeline of the producers: a tile row costs its nn / mod loads (coalesced) and then the dependent gather
+      // ref[j]; with thousands of frames in flight both come from HBM (thousands of cycles under load) while the chain
+      // needs a tile every TQ * 8 cycles.  Three tiles are in flight per thread -- loaded (t + 2), gathered (t + 1), written
+      // (t) -- in three register sets that trade roles by UNROLLING the tile loop three times, never by moving registers:
+      // a rotation by moves reads the registers of loads that were issued in the same iteration, and the compiler answers it
+      // with s_waitcnt vmcnt(0) -- every tile then waits for a full memory round trip and the prefetch is void (that was
+      // the state of round 2: "1 / 2 / 3 / 4 tiles ahead measure the same").  For the same reason nothing computes with a
+      // loaded value in the iteration that issued its load (the kept-pair test is applied where the row is gathered), and
+      // the tile barrier is a raw s_barrier behind an lgkmcnt wait: the LDS tile must be complete, the loads in flight and
+      // this phase's own global stores need not be (__syncthreads would drain them: it is a fence).
+      struct Row {                                         // one tile row of this thread on its way to LDS
+        int j;                                             // nearest reference index (valid from the gather on)
+        float d;                                           // SPEC: its squared distance
+        bool in;                                           // the row exists (below `rows`)
+        F3 m, r;                                           // model point, reference point
+      };
+      auto row_load = [&](Row &w, int t) {                 // issue only: nothing here reads what it loads
+        const int i = t * TQ + slot;
+        w.in = i < rows;
+        const int ic = min(i, rows - 1);                   // clamped: unused past the end
+        w.j = ld_u32(nn, ic);
+        w.d = SPEC ? ld_u32(nd, ic) : 0.0f;
+        w.m = ld3_u32(mod, ic);
+      };
+      auto row_gather = [&](Row &w) {                      // SPEC: nn[] holds the neighbour whatever its distance; the pair is kept
+        if (!(w.in && (!SPEC || w.d <= thr))) w.j = -1;    // if d <= dist_thr (:268; NaN = none found)
+        w.r = ld3_u32(ref, max(w.j, 0));
+      };
+      auto row_write = [&](const Row &w, int t) {
+        const bool have = w.j >= 0;                        // dropped pairs contribute an exact +0.0f: (+0) * (+0)
+        if (SPEC && have) ++kept;
+        float (*tile)[SH::TS] = S.prod[t & 1];
+        const float mm[3] = {have ? w.m.x : 0.0f, have ? w.m.y : 0.0f, have ? w.m.z : 0.0f};
+        const float rr[3] = {have ? w.r.x : 0.0f, have ? w.r.y : 0.0f, have ? w.r.z : 0.0f};
 #pragma unroll
-      for (int k = 0; k <= PD; ++k) { jq[k] = -1; mq[k][0] = mq[k][1] = mq[k][2] = 0.f; }
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int k = 0; k < PD; ++k) rq[k][0] = rq[k][1] = rq[k][2] = 0.f;
-      if (slot >= 0) {
-        // SPEC: nn[] holds the neighbour whatever its distance; the pair is kept if d <= dist_thr (:268; NaN = none found)
+          for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = mm[a] * rr[b];   // (*it_s) * (*it_ref).t()
 #pragma unroll
-        for (int k = 0; k <= PD; ++k) {
-          const int i0 = k * TQ + slot;
-          if (i0 < rows) {
-            jq[k] = ld_u32(nn, i0);
-            if (SPEC && !(ld_u32(nd, i0) <= thr)) jq[k] = -1;
-            const F3 v3_ = ld3_u32(mod, i0);
-            mq[k][0] = v3_.x; mq[k][1] = v3_.y; mq[k][2] = v3_.z;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < PD; ++k) {
-          const F3 v3_ = ld3_u32(ref, max(jq[k], 0));
-          rq[k][0] = v3_.x; rq[k][1] = v3_.y; rq[k][2] = v3_.z;
-        }
-      }
+        for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = mm[q]; tile[12 + q][slot] = rr[q]; }
+      };
+      auto tile_barrier = [&]() {                          // LDS writes of this wave complete, then the workgroup barrier
+        __builtin_amdgcn_s_waitcnt(0xC07F);                // s_waitcnt lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+      };
       const bool chain_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
-      if (FL_ICP_SPLIT && chain_wave) {
+      if (chain_wave) {
         // the chain wave's own loop: one barrier per tile like the producers' below
         for (int t = 0; t < ntiles; ++t) {
           if (t > 0 && threadIdx.x < 15)
             acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
-          __syncthreads();
+          tile_barrier();
         }
-      } else
-      for (int t = 0; t < ntiles; ++t) {
-        if (slot >= 0) {
-          const int i3 = min((t + PD + 1) * TQ + slot, rows - 1);     // clamped: unused past the end
-          const bool in3 = (t + PD + 1) * TQ + slot < rows;
-          int j3 = ld_u32(nn, i3);
-          const float d3 = SPEC ? ld_u32(nd, i3) : 0.0f;
-          const F3 m3v = ld3_u32(mod, i3);
-          j3 = in3 && (!SPEC || d3 <= thr) ? j3 : -1;
-          const F3 rNv = ld3_u32(ref, max(jq[PD], 0));   // the gather of tile t + PD
-          const bool have = jq[0] >= 0;                  // dropped pairs contribute an exact +0.0f: (+0) * (+0)
-          if (SPEC && have) ++kept;
-          float (*tile)[SH::TS] = S.prod[t & 1];
-          float mm[3], rr[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) { mm[q] = have ? mq[0][q] : 0.0f; rr[q] = have ? rq[0][q] : 0.0f; }
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) tile[a * 3 + b][slot] = mm[a] * rr[b];   // (*it_s) * (*it_ref).t()
-#pragma unroll
-          for (int q = 0; q < 3; ++q) { tile[9 + q][slot] = mm[q]; tile[12 + q][slot] = rr[q]; }
-#pragma unroll
-          for (int k = 0; k < PD; ++k) {
-            jq[k] = jq[k + 1];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) mq[k][q] = mq[k + 1][q];
+      } else if (slot >= 0) {
+        Row X, Y, Z;
+        row_load(X, 0);
+        row_load(Y, 1);
+        row_gather(X);
+        for (int t = 0; t < ntiles; t += 3) {
+          row_load(Z, t + 2); row_gather(Y); row_write(X, t);
+          tile_barrier();
+          if (t + 1 < ntiles) {
+            row_load(X, t + 3); row_gather(Z); row_write(Y, t + 1);
+            tile_barrier();
           }
-#pragma unroll
-          for (int k = 0; k + 1 < PD; ++k)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) rq[k][q] = rq[k + 1][q];
-          rq[PD - 1][0] = rNv.x; rq[PD - 1][1] = rNv.y; rq[PD - 1][2] = rNv.z;
-          jq[PD] = j3;
-          mq[PD][0] = m3v.x; mq[PD][1] = m3v.y; mq[PD][2] = m3v.z;
-        } else if (!FL_ICP_SPLIT && t > 0 && threadIdx.x < 15) {
-          acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+          if (t + 2 < ntiles) {
+            row_load(Y, t + 4); row_gather(X); row_write(Z, t + 2);
+            tile_barrier();
+          }
         }
-        __syncthreads();
+      } else {
+        for (int t = 0; t < ntiles; ++t) tile_barrier();   // a wave that neither chains nor produces (1024-thread workgroup)
       }
+      __syncthreads();                                     // (the loads still in flight belong to rows past the end)
     } else
     for (int t = 0; t < ntiles; ++t) {
       if (slot >= 0) {
@@ -2229,9 +2227,9 @@ void k_icp_pipeline(IcpArgs a)
   using SH = IcpSharedT<BS>;
   SH &S = *(SH *)icp_smem;
 #ifdef FL_ICP_PHASES
-  if (threadIdx.x == 0) S.tkernel = clock64();
+  if (threadIdx.x == 0) { S.tkernel = clock64(); S.wall0 = wall_clock64(); }
 #endif
-  const int job = blockIdx.x, rank = a.job.kind == 0 && !a.jobs ? job % a.ranks : 0;
+  const int job = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, rank = a.job.kind == 0 && !a.jobs ? job % a.ranks : 0;
   const int frame = a.job.kind == 0 ? (a.jobs ? a.jobs[job].frame : job / a.ranks) : job;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)job * a.ws_stride;
@@ -2382,6 +2380,15 @@ void k_icp_pipeline(IcpArgs a)
     for (int i = 0; i < 9; ++i) res->det.R_final[i] = (float)S.hist[16 + i];
     for (int i = 0; i < 3; ++i) res->det.T_final[i] = (float)S.hist[26 + i];
     for (int i = 0; i < 5; ++i) res->pose[11 + i] = (float)S.stime[i];   // the last five union classes (wider than 29 pixels) make room
+    // start / end of this workgroup on the 100 MHz wall clock (two 24-bit halves each: a float holds 24 bits), and its CU
+    {
+      const long long w1 = wall_clock64();
+      res->pose[0] = (float)((S.wall0 >> 24) & 0xffffff); res->pose[1] = (float)(S.wall0 & 0xffffff);
+      res->pose[2] = (float)((w1 >> 24) & 0xffffff); res->pose[3] = (float)(w1 & 0xffffff);
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      res->pose[4] = (float)(hwid & 0xffffff);
+    }
 #endif
   }
 }
@@ -2429,6 +2436,69 @@ extern "C" int fl_depth_to_3d(fl_context *ctx, const uint16_t *depth, int w, int
   return FL_OK;
 }
 
+// ---- longest job first ------------------------------------------------------------------------------------------------
+// A batch of a few thousand frames is two or three rounds of workgroups on the chip's slots, and a frame's refinement takes
+// time in proportion to its cloud (13 k - 17 k points on the bench scenes: lifetimes of 6.4 - 10.9 ms in one launch).  The
+// hardware deals workgroups to slots as they free up, in blockIdx order, so with jobs in frame order the last ones to start
+// are average jobs behind the slowest first-round ones, and a launch of 2048 frames took 20.0 ms for 2 x 8.5 ms of mean
+// work per slot (85 % of the slots' time used; profiles/README.md).  Dealt longest first, the long jobs run in the first
+// round and the short ones fill in behind them.  k_icp_count estimates a job's size as the number of pixels of its crop
+// that are valid in both depth images (what crop_clouds will keep); k_icp_order sorts the jobs by it, descending.
+__global__ __launch_bounds__(256) void k_icp_count(IcpArgs a, int *__restrict__ size)
+{
+  __shared__ int part[4];
+  const int job = blockIdx.x;
+  const uint8_t *fws = a.frame_ws + (size_t)job * a.frame_stride;
+  const int *counters = (const int *)(fws + a.off_count);
+  const fl_match *matches = (const fl_match *)(fws + a.off_match);
+  int n = 0;
+  if (!counters[2] && counters[1] > 0) {
+    const fl_match best = matches[0];
+    const int g = a.class_first[best.class_idx] + best.template_id;
+    const FlPyrInfo pi = a.pyr[g];
+    const uint16_t *model = a.depth_ptrs[g];
+    const uint16_t *scene = (const uint16_t *)((const uint8_t *)a.scene_base + (size_t)job * a.scene_stride);
+    const int cw = pi.width0, ch = pi.height0;
+    const bool ok = model && pi.off_x0 >= 0 && pi.off_y0 >= 0 && best.x >= 0 && best.y >= 0 && cw > 0 && ch > 0 && pi.off_x0 + cw <= a.w &&
+                    pi.off_y0 + ch <= a.h && best.x + cw <= a.w && best.y + ch <= a.h;
+    if (ok)
+      for (int y = threadIdx.x >> 6; y < ch; y += 4)
+        for (int x = threadIdx.x & 63; x < cw; x += 64) {
+          const unsigned ds = scene[(size_t)(best.y + y) * a.w + best.x + x], dm = model[(size_t)(pi.off_y0 + y) * a.w + pi.off_x0 + x];
+          n += (ds != 0 && ds <= 900 && dm != 0 && dm <= 9004) ? 1 : 0;      // z <= 900 mm in both (the render is in 0.1 mm): an estimate
+        }
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) n += __shfl_xor(n, sft, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) size[job] = part[0] + part[1] + part[2] + part[3];
+}
+
+// order[0 .. n) = the jobs by size, descending (ties by job index): one workgroup, bitonic sort of 64-bit keys in LDS
+#define ICP_ORDER_MAX 8192
+__global__ __launch_bounds__(1024) void k_icp_order(const int *__restrict__ size, int n, int *__restrict__ order)
+{
+  extern __shared__ unsigned long long okeys[];
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = threadIdx.x; i < m; i += 1024)
+    okeys[i] = i < n ? ((unsigned long long)(unsigned)(0x7fffffff - size[i]) << 32) | (unsigned)i : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= m; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < m; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = okeys[i], y = okeys[l];
+          if (((i & k) == 0) == (x > y)) { okeys[i] = y; okeys[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < n; i += 1024) order[i] = (int)(unsigned)(okeys[i] & 0xffffffffull);
+}
+
 #define ICP_WPE_MAX 5
 static_assert(sizeof(IcpSharedT<ICP_BS_SMALL>) + 16 <= 160 * 1024 / ICP_WPE_MAX, "IcpSharedT<256> must leave room for 5 workgroups per CU");
 static_assert(sizeof(IcpSharedT<ICP_BS_WIDE>) + 16 <= 160 * 1024, "IcpSharedT<1024> must fit the CU's LDS");
@@ -2455,9 +2525,10 @@ static bool icp_wide(fl_context *ctx, int n_jobs)
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   return n_jobs <= 2 * cus;
 }
-// Workgroups per CU of the 256-thread parity kernel: whichever of 4 and 5 needs less time for n_jobs by the measured cost of
-// a full round (5 per CU: 1.20 x the time of 4 per CU for 1.25 x the frames; 360 templates, one box: 2560 frames 24.97 ms
-// against 2048 frames 20.78 ms).  FL_ICP_OCC=4/5 forces one (dev knob).
+// Workgroups per CU of the 256-thread parity kernel: whichever of 4 and 5 needs fewer rounds by the measured cost of a full
+// round (5 per CU: about 1.25 x the time of 4 per CU for 1.25 x the frames -- the 96-VGPR build spills more; round 3, jobs
+// dealt longest first, ICP ms per launch at 4 / 5 per CU: 2560 frames 24.9 / 24.0, 3840: 33.4 / 33.2, 4096: 35.0 / 36.5,
+// 5120: 46.7 / 47.7, 6144: 56.0 / 58.5).  FL_ICP_OCC=4/5 forces one (dev knob).
 static int icp_small_wpe(fl_context *ctx, int n_jobs)
 {
   const char *env = getenv("FL_ICP_OCC");
@@ -2466,7 +2537,7 @@ static int icp_small_wpe(fl_context *ctx, int n_jobs)
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int r4 = (n_jobs + 4 * cus - 1) / (4 * cus), r5 = (n_jobs + 5 * cus - 1) / (5 * cus);
-  return 1.20 * r5 < 1.0 * r4 ? 5 : 4;
+  return 1.25 * r5 < 1.0 * r4 ? 5 : 4;
 }
 template <int MODE>
 static int icp_launch_mode(fl_context *ctx, int n_jobs, const IcpArgs &a)
@@ -2718,6 +2789,23 @@ int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsic
   a.poses = det->d_poses;
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = det->d_results;
+  // more jobs than the chip has slots: deal them longest first (see k_icp_order); FL_ICP_ORDER=0 keeps the frame order (dev knob)
+  int cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const char *env = getenv("FL_ICP_ORDER");
+  if (n_frames > 4 * cus && n_frames <= ICP_ORDER_MAX && !(env && env[0] == '0')) {
+    if (!det->d_icp_order) FL_HIP(ctx, hipMalloc((void **)&det->d_icp_order, sizeof(int) * 2 * (size_t)det->max_batch));
+    int *d_size = det->d_icp_order + det->max_batch;
+    hipLaunchKernelGGL(k_icp_count, dim3(n_frames), dim3(256), 0, ctx->stream, a, d_size);
+    int m = 1;
+    while (m < n_frames) m <<= 1;
+    FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * ICP_ORDER_MAX)));
+    hipLaunchKernelGGL(k_icp_order, dim3(1), dim3(1024), sizeof(unsigned long long) * (size_t)m, ctx->stream, (const int *)d_size, n_frames,
+                       det->d_icp_order);
+    FL_HIP(ctx, hipGetLastError());
+    a.order = det->d_icp_order;
+  }
   return icp_launch(ctx, n_frames, a);
 }
 

@@ -167,6 +167,7 @@ struct fl_detector {
   bool last_refinable = false;           // the last batch came from a batch submit (stage_and_match) and its depth frames are still where
                                          // last_depth_base says: only then may fl_refine_matches / fl_export_topk_batch follow
 
+  int *d_icp_order = nullptr;            // ICP launch: job order (longest first) + the jobs' size estimates, 2 * max_batch ints, on first use
   // template-sharded recognition on the device: the jobs fl_select_best_batch chose (frame = -1: not this rank's)
   FlRefineJob *d_jobs = nullptr;         // max_batch, allocated on first use
   int selected_frames = 0;               // frames of the last fl_select_best_batch (0: none pending)
