@@ -74,10 +74,6 @@
 #ifndef FL_ICP_NBQ
 #define FL_ICP_NBQ 4              // organised search: candidate positions fetched per batch (4 VGPRs each)
 #endif
-#ifndef FL_ICP_NST
-#define FL_ICP_NST 6              // organised search: a staged window travels through up to 6 float4 registers per lane (the whole LDS
-                                  // share of the wave: 367 points; 4 -> 20.95 vs 21.59 ms per 2048 frames, more windows scanned from L2)
-#endif
 #ifndef FL_ICP_PD
 #define FL_ICP_PD 1               // chain phases, parity mode: tiles whose loads a producer thread keeps in flight (phase A2: the
                                   // dependent gather ref[nn[i]] runs FL_ICP_PD tiles ahead, nn / mod one more; phase B: mod / ref / bnd).
@@ -96,13 +92,7 @@
 #define FL_ICP_SPEC 1             // parity mode, organised search: the next iteration's search runs while the chain wave adds dist_mean
                                   // (1: in the 1024-thread kernel, 2: in both, 0: off)
 #endif
-#ifndef FL_ICP_SEARCH
-#define FL_ICP_SEARCH 3           // organised search, the step's overhead around the distance scan: 1 = round 2 (union window staged at its
-                                  // own width, six serial wave reductions), 2 = staged rows of 16 / 32 / 64 points (no address arithmetic
-                                  // per staged point), five interleaved reductions, batches per row by ballot; 3 = 2 software-pipelined
-                                  // over its steps (the next step's rectangle fetched by LDS-DMA while this one is scanned), 256-thread kernels
-#endif
-#define ICP_STAGE_CAP 384         // points a wave stages per search step (FL_ICP_SEARCH 2): six passes of 64
+#define ICP_STAGE_CAP 384         // points a wave stages per search step: six passes of 64
 #ifndef FL_ICP_NB
 #define FL_ICP_NB 10              // candidates fetched per round trip of the NN search (measured: 8..20)
 #endif
@@ -479,37 +469,6 @@ __device__ __forceinline__ T ld_u32(const T *__restrict__ base, int idx)
   return *(const T *)((const char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
 }
 
-// Vector-memory operations as inline assembly: the compiler's s_waitcnt bookkeeping does not see them (the pipelined
-// organised search counts their completion itself, see FL_ICP_SEARCH 3).  A load's destination is valid only after the
-// s_waitcnt that retires it; nothing may read or copy it before.
-typedef float f3v __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void asm_ld_i32(int &dst, const int *base, int idx)
-{
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"((unsigned)idx * 4u), "s"(base) : "memory");
-}
-__device__ __forceinline__ void asm_ld_f32(float &dst, const float *base, int idx)
-{
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"((unsigned)idx * 4u), "s"(base) : "memory");
-}
-__device__ __forceinline__ void asm_ld_f3(f3v &dst, const float *base, int idx)
-{
-  asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(dst) : "v"((unsigned)idx * 12u), "s"(base) : "memory");
-}
-struct StorePlain {                                      // st(base, i, v): base[i] = v
-  __device__ __forceinline__ void operator()(int *base, int i, int v) const { base[i] = v; }
-  __device__ __forceinline__ void operator()(float *base, int i, float v) const { base[i] = v; }
-};
-struct StoreAsm {
-  __device__ __forceinline__ void operator()(int *base, int i, int v) const
-  {
-    asm volatile("global_store_dword %0, %1, %2" : : "v"((unsigned)i * 4u), "v"(v), "s"(base) : "memory");
-  }
-  __device__ __forceinline__ void operator()(float *base, int i, float v) const
-  {
-    asm volatile("global_store_dword %0, %1, %2" : : "v"((unsigned)i * 4u), "v"(v), "s"(base) : "memory");
-  }
-};
-
 // one 12-byte load (global_load_dwordx3) for a point instead of three dword loads: the phases are bound by the
 // number of vector-memory instructions as much as by anything else
 struct F3 { float x, y, z; };
@@ -814,33 +773,8 @@ __device__ __forceinline__ int cvt_i32_sat(float f)
 // The crop pixels whose points can lie within distance r of q: a point (X, Y, Z) of pixel (su, sv) satisfies
 // su - cx = X fx / Z up to float rounding (it was generated as X = ((su - cx) / fx) Z), and |X - qx|, |Z - qz| <= r.
 // The 0.01-pixel slop is an order of magnitude above that rounding (5e-7 relative on |su - cx| <= 2000 pixels).  An empty window has u_lo > u_hi.
-__device__ __forceinline__ void org_window(const OrgGeom &g, float qx, float qy, float qz, float r, int &u_lo, int &u_hi, int &v_lo,
-                                           int &v_hi)
-{
-  u_lo = 0; u_hi = g.cw - 1; v_lo = 0; v_hi = g.ch - 1;
-  const float zlo = qz - r, zhi = qz + r;
-  if (isfinite(r) && zlo > 1.0f) {                       // otherwise the whole crop (valid points have 0 < Z <= 900)
-    const float ilo = __builtin_amdgcn_rcpf(zlo), ihi = __builtin_amdgcn_rcpf(zhi);
-    const float xlo = qx - r, xhi = qx + r, ylo = qy - r, yhi = qy + r;
-    // integer pixels u with t_lo - slop <= u <= t_hi + slop: ceil of the lower end, floor of the upper end
-    const float ful = ceilf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - g.offu - 0.01f);
-    const float fuh = floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - g.offu + 0.01f);
-    const float fvl = ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - g.offv - 0.01f);
-    const float fvh = floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - g.offv + 0.01f);
-    // to integers first (clamped far outside any crop), then compared with the crop size as integers: cw and ch are
-    // wave-uniform and stay scalar operands
-    const int iul = (int)fminf(fmaxf(ful, -1.0e6f), 1.0e6f), iuh = (int)fminf(fmaxf(fuh, -1.0e6f), 1.0e6f);
-    const int ivl = (int)fminf(fmaxf(fvl, -1.0e6f), 1.0e6f), ivh = (int)fminf(fmaxf(fvh, -1.0e6f), 1.0e6f);
-    if (iuh < 0 || iul > g.cw - 1 || ivh < 0 || ivl > g.ch - 1 || iul > iuh || ivl > ivh) { u_lo = 1; u_hi = 0; return; }
-    u_lo = max(iul, 0);
-    u_hi = min(iuh, g.cw - 1);
-    v_lo = max(ivl, 0);
-    v_hi = min(ivh, g.ch - 1);
-  }
-}
-
-// org_window with the constants folded and the clamps left to the saturating conversion: returns whether the window holds a pixel.
-// cul / cuh = offu +- slop, cvl / cvh = offv +- slop (wave-uniform)
+// (the constants folded -- cul / cuh = offu +- slop, cvl / cvh = offv +- slop, wave-uniform -- and the clamping left to the
+// saturating float -> int conversion; returns whether the window holds a pixel)
 __device__ __forceinline__ bool org_window2(const OrgGeom &g, float cul, float cuh, float cvl, float cvh, float qx, float qy, float qz, float r,
                                             int &u_lo, int &u_hi, int &v_lo, int &v_hi)
 {
@@ -1116,146 +1050,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 
   // ---- organised search: PointsCorresponding (:193-279) for every model point, exact 1-NN within min(bnd[i], r_lim) ----
   // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  Steps are claimed from a
-  // workgroup counter (S.a1_next, reset by the caller) in parity mode, four steps ahead of the one being scanned, so that
-  // the loads of the next steps (perm -> mod, bnd) are in flight and a wave that joins late (the chain wave) simply takes
-  // what is left.
-  // (Fetching the next step's window ahead of time -- through registers, or by LDS-DMA into a second buffer -- measured no
-  // faster: the phase is bound by VALU issue, not by the staging round trip; profiles/README.md.)
+  // workgroup counter (S.a1_next, reset by the caller) where a wave joins late (SPEC), four steps ahead of the one being
+  // scanned, so that the loads of the next steps (perm -> mod, bnd) are in flight; otherwise wave w takes steps w, w + NW, ...
   // found(active, i, qx, qy, qz, j, d): j = -1, d = NaN when no reference point lies within the radius.
-  auto org_search = [&](const float r_lim, const bool poll_stop, auto &&found) {
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    constexpr int NST = FL_ICP_NST;                             // float4 registers per lane that hold a window on its way to LDS
-    constexpr int CAPL = (int)(sizeof(S.prod) / 16) / NW;       // points a wave's share of the chain tiles holds
-    constexpr int CAPW = CAPL < 64 * NST ? CAPL : 64 * NST;     // points a wave stages: larger unions are scanned from L2
-    float4 *stage = (float4 *)&S.prod[0][0][0] + wv * CAPW;
-    const float4 *refimg = sref;
-    const int last_s = n_model - 1;
-    float4 Rlast = make_float4(0.f, 0.f, 0.f, 0.f);       // the last point of the window being staged (lanes < NN_OVERRUN)
-    struct Win {
-      int u_lo, u_hi, v_lo, v_hi;        // this lane's window (crop pixels); a lane without one looks at (U0, V0)
-      int U0, V0, W, H, area, maxw, maxh;   // wave-uniform: union rectangle and the largest lane window
-      bool any, staged;                  // wave-uniform: some lane has a window; the union fits the LDS share
-    };
-    auto make_window = [&](const F3 &q, float b, bool queryable, Win &w) {
-      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
-      if (queryable) org_window(og, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_lim)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_lim
-      const bool some = u_lo <= u_hi;
-      const int U0 = wave_min_i(some ? u_lo : 0x7fffffff), U1 = wave_max_i(some ? u_hi : -1);
-      w.any = U1 >= U0;
-      w.U0 = U0; w.V0 = 0; w.W = 1; w.H = 0; w.area = 0; w.maxw = 0; w.maxh = 0; w.staged = false;
-      if (w.any) {
-        const int V0 = wave_min_i(some ? v_lo : 0x7fffffff), V1 = wave_max_i(some ? v_hi : -1);
-        w.maxw = wave_max_i(u_hi - u_lo + 1);
-        w.maxh = wave_max_i(v_hi - v_lo + 1);
-        if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one staged point: a real
-                                                             // reference point beyond their radius, which the gate drops
-        w.V0 = V0;
-        w.W = U1 - U0 + 1;
-        w.H = V1 - V0 + 1;
-        w.area = w.W * w.H;
-        w.staged = w.area + NN_OVERRUN <= CAPW;
-      }
-      w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
-    };
-    auto issue_stage = [&](const Win &w, float4 (&R)[NST]) {
-      // slot k = lane + 64 t holds point (k / W, k % W) of the union rectangle: one division (by reciprocal: exact for
-      // k < 2^20, k + 0.5 keeps clear of the integers) for t = 0, then (row, col) advance by 64 slots incrementally;
-      // all products fit 24 bits
-      const float invW = 1.0f / (float)w.W;
-      int row = (int)(((float)lane + 0.5f) * invW), col = lane - row * w.W;
-      const int drow = (int)(64.5f * invW), dcol = 64 - drow * w.W;      // 64 = drow * W + dcol (wave-uniform)
-      int idx = (int)__umul24((unsigned)(w.V0 + row), (unsigned)og.cw) + w.U0 + col;
-      const int didx = (int)__umul24((unsigned)drow, (unsigned)og.cw) + dcol;
-#pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        if (lane + 64 * j < w.area) R[j] = ld_u32(refimg, idx);
-        col += dcol;
-        idx += didx;
-        if (col >= w.W) { col -= w.W; idx += og.cw - w.W; }
-      }
-      // the overrun guard behind the window: NN_OVERRUN copies of its last point (lanes 0 .. NN_OVERRUN - 1 write them)
-      if (lane < NN_OVERRUN) Rlast = ld_u32(refimg, (int)__umul24((unsigned)(w.V0 + w.H - 1), (unsigned)og.cw) + w.U0 + w.W - 1);
-    };
-    auto write_stage = [&](const Win &w, const float4 (&R)[NST]) {
-#pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        const int k = lane + 64 * j;
-        if (k < w.area) stage[k] = R[j];
-      }
-      if (lane < NN_OVERRUN) stage[w.area + lane] = Rlast;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    // Steps are claimed from the workgroup counter only where a wave joins late (SPEC); the modes that keep per-thread
-    // partial sums need a fixed assignment of queries to threads to be deterministic: wave w takes steps w, w + NW, ...
-    constexpr int stride = NW * 64;
-    int static_next = wv * 64 + 4 * stride;
-    auto claim = [&](int count) {                          // `count` queries off the workgroup's list (wave-uniform result)
-      int v = 0;
-      if (lane == 0) v = atomicAdd(&S.a1_next, count);
-      return __builtin_amdgcn_readfirstlane(v);
-    };
-    auto next_step = [&]() {
-      if (SPEC) return claim(64);
-      const int v = static_next;
-      static_next += stride;
-      return v;
-    };
-    float4 R[NST];
-    Win wc;
-    const int sdist = SPEC ? 64 : stride;
-    int sb0 = SPEC ? claim(256) : wv * 64, sb1 = sb0 + sdist, sb2 = sb0 + 2 * sdist, sb3 = sb0 + 3 * sdist;
-    int i_c = ld_u32(perm, min(sb0 + lane, last_s));
-    int i_n = ld_u32(perm, min(sb1 + lane, last_s));
-    int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
-    F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
-    float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
-    auto queryable_at = [&](int s, const F3 &q) { return s + lane < n_model && r_lim >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z); };
-    while (sb0 < n_model) {
-      if (poll_stop && *(volatile int *)&S.stop) break;
-      const int sb4 = next_step();
-      make_window(q_c, b_c, queryable_at(sb0, q_c), wc);
-      if (wc.any && wc.staged) { issue_stage(wc, R); write_stage(wc, R); }
-      const F3 q_nn = ld3_u32(mod, i_nn);
-      const float b_nn = ld_u32(bnd, i_nn);
-      const int i_nnn = ld_u32(perm, min(sb3 + lane, last_s));
-      const int i = i_c;
-      const float qx = q_c.x, qy = q_c.y, qz = q_c.z;
-      const bool active = sb0 + lane < n_model;
-      const bool queryable = queryable_at(sb0, q_c);
-      int j = -1;
-      float d = NAN;
-      if (wc.any) {                                    // wave-uniform: at least one lane has a window
-#ifdef FL_ICP_PHASES
-        if (lane == 0) {
-          atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
-          atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(wc.maxw * wc.maxh));
-          atomicAdd((unsigned long long *)&S.tacc[10], wc.staged ? 0ull : 1ull);
-          atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)wc.area);
-          if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(wc.maxw * wc.maxh));
-          const int wcl = wc.W <= 13 ? 0 : (wc.W <= 29 ? 1 : (wc.W <= 61 ? 2 : 3)), hcl = wc.H <= 5 ? 0 : (wc.H <= 10 ? 1 : (wc.H <= 20 ? 2 : 3));
-          atomicAdd(&S.hist[wcl * 4 + hcl], 1u);
-          atomicAdd(&S.hist[16 + min(wc.maxh, 10) - 1], 1u);
-          atomicAdd(&S.hist[26 + (wc.maxw <= 4 ? 0 : (wc.maxw <= 8 ? 1 : (wc.maxw <= 12 ? 2 : 3)))], 1u);
-        }
-#endif
-        unsigned long long best;
-        if (wc.staged)
-          best = org_scan([&](int idx) { return stage[idx]; }, wc.W, wc.U0, wc.V0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw, wc.maxh);
-        else
-          best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, wc.u_lo, wc.u_hi, wc.v_lo, wc.v_hi, wc.maxw,
-                          wc.maxh);
-        if (queryable) NN_UNPACK(best, &j, &d)
-      }
-      found(active, i, qx, qy, qz, j, d, StorePlain());
-      i_c = i_n; q_c = q_n; b_c = b_n;
-      i_n = i_nn; q_n = q_nn; b_n = b_nn;
-      i_nn = i_nnn;
-      sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
-    }
-  };
-  // FL_ICP_SEARCH 2 -- the same search with less work around the distance scan of a step (the scan itself is unchanged):
+  // Around the distance scan of a step (which is what the step is for: 4 rows x 46 instructions per batch of four
+  // positions) round 2 spent as many instructions again; what is left of that:
   //  * the union rectangle is staged in whole passes of 64 points, as many as it needs (a compile-time count per case), the
   //    point of a slot by a reciprocal multiply: no division, no per-pass predicate, no separate guard points (measured:
   //    rows padded to 16 / 32 / 64 points need no address arithmetic at all, but nine steps in ten are 14 - 29 pixels wide
@@ -1263,7 +1062,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   //  * the five wave reductions (union rectangle, tallest lane window) are interleaved (wave_max_multi), the batches per
   //    row come from two ballots;
   //  * the window arithmetic has its constants folded and leaves the clamping to the saturating float -> int conversion.
-  auto org_search2 = [&](const float r_lim, const bool poll_stop, auto &&found) {
+  auto org_search = [&](const float r_lim, const bool poll_stop, auto &&found) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     static_assert(sizeof(S.prod) + sizeof(S.dtile) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
     static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
@@ -1291,6 +1090,13 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
     F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
     float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
+    // A step's results are handed to found() (which stores them) at the head of the NEXT step, in front of that step's
+    // staging loads: vmcnt counts loads and stores in one in-order queue, so stores issued at the end of a step were what the
+    // wait at the head of the next one waited for (20 % of the phase); issued here, the wait that follows them is the one
+    // for the staging loads, which covers them for free.
+    bool pend = false, p_active = false;
+    int p_i = 0, p_j = -1;
+    float p_qx = 0.f, p_qy = 0.f, p_qz = 0.f, p_d = NAN;
 #ifdef FL_ICP_PHASES
     long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = clock64();
 #define ST_STAMP(k) { const long long now_ = clock64(); st_acc[k] += now_ - st_last; st_last = now_; }
@@ -1306,6 +1112,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       asm volatile("" :: "v"(qx), "v"(b_c));             // the query and its bound have arrived
 #endif
       ST_STAMP(0)
+      if (pend) { found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d); pend = false; }
       const bool active = sb0 + lane < n_model;
       const bool queryable = active && r_lim >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz);
       // ---- this lane's window, the union rectangle, the tallest window ----
@@ -1411,231 +1218,25 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 #endif
         ST_STAMP(3)
       }
-      found(active, i, qx, qy, qz, j, d, StorePlain());
+      pend = true; p_active = active; p_i = i; p_qx = qx; p_qy = qy; p_qz = qz; p_j = j; p_d = d;
       i_c = i_n; q_c = q_n; b_c = b_n;
       i_n = i_nn; q_n = q_nn; b_n = b_nn;
       i_nn = i_nnn;
       sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
       ST_STAMP(4)
     }
+    if (pend) found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d);
 #ifdef FL_ICP_PHASES
     if (lane == 0)
       for (int k = 0; k < 5; ++k) atomicAdd(&S.stime[k], (unsigned long long)st_acc[k]);
 #endif
 #undef ST_STAMP
   };
-  // FL_ICP_SEARCH 3 -- the same search, software-pipelined over its steps.  The stamps of a step (profiles/README.md) show
-  // what a wave waits for: the staging loads' round trip (47 % of the phase: the reference images of a few thousand frames
-  // live in HBM) and, at the loop's head, the stores and prefetches of the step before (20 %: vmcnt counts loads and stores
-  // in one in-order queue); window arithmetic and reductions are 6 %, the scan 24 %.  So the union rectangle of step k + 1 is
-  // fetched while step k is scanned: window, reductions and rectangle of the NEXT step are computed first, its points go
-  // from the image straight into the wave's other LDS buffer by LDS-DMA (global_load_lds_dwordx4: no destination
-  // registers, no ds_write), and the wait for them sits at the head of the next step, one whole scan later.  A step's
-  // results are stored at the head of the step after it, in front of that step's transfers.  Every vector-memory operation
-  // of the loop's common path is inline assembly on purpose: the compiler's s_waitcnt bookkeeping does not see them, so it
-  // neither waits for the transfers in front of the scan's ds_reads nor turns its own counted waits into waits for
-  // operations it cannot count; their completion is counted here: ONE s_waitcnt vmcnt(0) per step, at its head, for
-  // operations that were issued a whole scan earlier.  A rectangle of more than three passes of 64 points, or the step
-  // after one (it occupies both buffers), is staged the synchronous way of FL_ICP_SEARCH 2.
-  auto org_search3 = [&](const float r_lim, const bool poll_stop, auto &&found) {
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    static_assert(sizeof(S.prod) + sizeof(S.dtile) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
-    static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
-    constexpr int DP = ICP_STAGE_CAP / 128;                // passes of 64 points per LDS buffer; a wave's region is two buffers
-    float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
-    const unsigned stage_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)stage);   // LDS byte address (flat aperture: low word)
-    const float4 *refimg = sref;
-    const int last_s = n_model - 1, last_pt = og.cw * og.ch + NN_OVERRUN - 1;
-    const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
-    constexpr int stride = NW * 64;
-    int static_next = wv * 64 + 4 * stride;
-    auto claim = [&](int count) {                          // `count` queries off the workgroup's list (wave-uniform result)
-      int v = 0;
-      if (lane == 0) v = atomicAdd(&S.a1_next, count);
-      return __builtin_amdgcn_readfirstlane(v);
-    };
-    auto next_step = [&]() {
-      if (SPEC) return claim(64);
-      const int v = static_next;
-      static_next += stride;
-      return v;
-    };
-    struct Prep {                                          // a step whose window arithmetic is done
-      int u_lo, u_hi, v_lo, v_hi;                          // this lane's window (a lane without one looks at (U0, V0))
-      int U0, V0, W, maxh, nbw, npneed;                    // wave-uniform: union rectangle, tallest window, batches per row, passes
-      bool any;                                            // wave-uniform: some lane has a window
-    };
-    auto prepare = [&](float qx, float qy, float qz, float b, bool queryable, Prep &w) {
-      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
-      bool some = false;
-      if (queryable) some = org_window2(og, cul, cuh, cvl, cvh, qx, qy, qz, nn_radius(qx, qy, qz, fminf(b, r_lim)), u_lo, u_hi, v_lo, v_hi);   // NaN bnd -> r_lim
-      const int big = 0x3fffffff;
-      int red[5] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0};
-      wave_max_multi(red);
-      const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3];
-      w.any = U1 >= U0;
-      w.U0 = U0; w.V0 = V0; w.W = 1; w.maxh = red[4]; w.nbw = 1; w.npneed = 0;
-      if (w.any) {
-        if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }     // lanes without a window look at one point of the union: a real
-                                                             // reference point beyond their radius, which the gate drops
-        const int wl = u_hi - u_lo;
-        // 4-wide batches per row of the widest lane window: 1 or 2 by ballot, beyond that by a reduction (first iterations)
-        if (__ballot(wl > 3) != 0ull) w.nbw = __ballot(wl > 7) == 0ull ? 2 : (wave_max_i(wl) >> 2) + 1;
-        w.W = U1 - U0 + 1;
-        w.npneed = (w.W * (V1 - V0 + 1) + 3 + 63) >> 6;     // passes of 64 slots: the rectangle + the 3 slots a batch may overrun it by
-      }
-      w.u_lo = u_lo; w.u_hi = u_hi; w.v_lo = v_lo; w.v_hi = v_hi;
-    };
-    // image index of staged slot k = lane + 64 p of the rectangle (see FL_ICP_SEARCH 2)
-    auto slot_index = [&](const Prep &w, float invW, int base, int p) {
-      const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * w.W;
-      return min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
-    };
-    auto issue_dma = [&](const Prep &w, int buf) {         // up to DP passes into buffer `buf`, not waited for
-      const float invW = uniform_f(__builtin_amdgcn_rcpf((float)w.W));
-      const int base = (int)__umul24((unsigned)w.V0, (unsigned)og.cw) + w.U0;
-#pragma unroll
-      for (int p = 0; p < DP; ++p) {
-        if (p < w.npneed) {
-          const float4 *src = refimg + (unsigned)slot_index(w, invW, base, p);
-          const unsigned dst = stage_lds + (unsigned)(buf * DP + p) * 1024u;
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        }
-      }
-    };
-    auto stage_sync = [&](const Prep &w, float4 *dst) {    // the synchronous way: registers, ds_write, wait
-      const float invW = uniform_f(__builtin_amdgcn_rcpf((float)w.W));
-      const int base = (int)__umul24((unsigned)w.V0, (unsigned)og.cw) + w.U0;
-      auto passes = [&](auto np_) {
-        constexpr int NP = decltype(np_)::value;
-        float4 R[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) R[p] = ld_u32(refimg, slot_index(w, invW, base, p));
-#pragma unroll
-        for (int p = 0; p < NP; ++p) dst[lane + 64 * p] = R[p];
-      };
-      if (w.npneed <= 2) passes(std::integral_constant<int, 2>());
-      else if (w.npneed == 3) passes(std::integral_constant<int, 3>());
-      else if (w.npneed == 4) passes(std::integral_constant<int, 4>());
-      else passes(std::integral_constant<int, 6>());
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    auto scan_staged = [&](const Prep &w, const float4 *buf, float qx, float qy, float qz) {
-      unsigned long long best = NN_KEY_NONE;
-      const int wl = w.u_hi - w.u_lo, hl = w.v_hi - w.v_lo;
-      const float4 *row0 = buf + (w.v_lo - w.V0) * w.W + (w.u_lo - w.U0);
-      if (w.nbw == 1) {                                    // every lane's window is at most 4 wide: one batch per row
-        for (int dv = 0; dv < w.maxh; ++dv) {
-          const float4 *bp = row0 + min(dv, hl) * w.W;
-          float4 cur[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) cur[e] = bp[e];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
-        }
-      } else {
-        const int wlc = max(wl - 3, 0);
-        for (int dv = 0; dv < w.maxh; ++dv) {
-          const float4 *rowp = row0 + min(dv, hl) * w.W;
-          for (int du = 0; du < 4 * w.nbw; du += 4) {
-            const float4 *bp = rowp + min(du, wlc);
-            float4 cur[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cur[e] = bp[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
-          }
-        }
-      }
-      return best;
-    };
-    const int sdist = SPEC ? 64 : stride;
-    int sb0 = SPEC ? claim(256) : wv * 64, sb1 = sb0 + sdist, sb2 = sb0 + 2 * sdist, sb3 = sb0 + 3 * sdist;
-    auto queryable_at = [&](int sb, float qx, float qy, float qz) { return sb + lane < n_model && r_lim >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz); };
-    // Register pipeline of the queries: the index of step k + 3 and the point and bound of step k + 2 are loaded during step
-    // k into in_i / in_q / in_b, which nothing reads before the s_waitcnt at the head of step k + 1; only there are they
-    // rotated into the registers the next steps compute with.
-    int i_c = 0, i_n, i_nn, in_i;
-    float qcx = 0.f, qcy = 0.f, qcz = 0.f, qnx, qny, qnz, b_n, in_b;
-    f3v in_q;
-    {
-      const int i0 = ld_u32(perm, min(sb0 + lane, last_s)), i1 = ld_u32(perm, min(sb1 + lane, last_s));
-      in_i = ld_u32(perm, min(sb2 + lane, last_s));
-      const F3 q0 = ld3_u32(mod, i0), q1 = ld3_u32(mod, i1);
-      i_n = i0; qnx = q0.x; qny = q0.y; qnz = q0.z; b_n = ld_u32(bnd, i0);
-      i_nn = i1; in_q.x = q1.x; in_q.y = q1.y; in_q.z = q1.z; in_b = ld_u32(bnd, i1);
-    }
-    bool pend = false, p_active = false;                   // the previous step's result, not yet handed to found()
-    int p_i = 0, p_j = -1;
-    float p_qx = 0.f, p_qy = 0.f, p_qz = 0.f, p_d = NAN;
-    Prep cur, nxt;
-    bool nxt_pre = false;                                  // the next step's rectangle is being fetched into its buffer by LDS-DMA
-    int nxt_buf = 0;
-    nxt.any = false; nxt.npneed = 0; nxt.u_lo = nxt.u_hi = nxt.v_lo = nxt.v_hi = 0; nxt.U0 = nxt.V0 = 0; nxt.W = 1; nxt.maxh = 0; nxt.nbw = 1;
-    if (sb0 < n_model) prepare(qnx, qny, qnz, b_n, queryable_at(sb0, qnx, qny, qnz), nxt);
-    while (sb0 < n_model) {
-      if (poll_stop && *(volatile int *)&S.stop) break;
-      const int sb4 = next_step();
-      // everything the step before issued has landed: this step's rectangle (LDS-DMA), the queries of the next two steps
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_q), "+v"(in_b), "+v"(in_i) : : "memory");
-      __builtin_amdgcn_wave_barrier();
-      cur = nxt;
-      const bool cur_pre = nxt_pre;
-      const int cur_buf = nxt_buf;
-      i_c = i_n; qcx = qnx; qcy = qny; qcz = qnz;
-      i_n = i_nn; qnx = in_q.x; qny = in_q.y; qnz = in_q.z; b_n = in_b;
-      i_nn = in_i;
-      // the loads of the steps after next, then the results of the step before, then the next step's rectangle
-      asm_ld_f3(in_q, mod, i_nn);
-      asm_ld_f32(in_b, bnd, i_nn);
-      asm_ld_i32(in_i, perm, min(sb3 + lane, last_s));
-      if (pend) { found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d, StoreAsm()); pend = false; }
-      nxt.any = false; nxt.npneed = 0;
-      nxt_pre = false;
-      nxt_buf = cur_buf ^ 1;
-      if (sb1 < n_model) {
-        prepare(qnx, qny, qnz, b_n, queryable_at(sb1, qnx, qny, qnz), nxt);
-        if (nxt.any && nxt.npneed <= DP && (!cur.any || cur.npneed <= DP)) {   // fits one buffer, and this step leaves that buffer alone
-          issue_dma(nxt, nxt_buf);
-          nxt_pre = true;
-        }
-      }
-      // this step
-      const bool active = sb0 + lane < n_model;
-      int j = -1;
-      float d = NAN;
-      if (cur.any) {
-        unsigned long long best;
-        if (cur_pre) {
-          best = scan_staged(cur, stage + cur_buf * (DP * 64), qcx, qcy, qcz);
-        } else if (cur.npneed <= 2 * DP) {
-          float4 *dst = stage + (cur.npneed <= DP ? cur_buf * (DP * 64) : 0);
-          stage_sync(cur, dst);
-          best = scan_staged(cur, dst, qcx, qcy, qcz);
-        } else {
-          best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qcx, qcy, qcz, cur.u_lo, cur.u_hi, cur.v_lo, cur.v_hi, 4 * cur.nbw, cur.maxh);
-        }
-        if (queryable_at(sb0, qcx, qcy, qcz)) NN_UNPACK(best, &j, &d)
-      }
-      pend = true; p_active = active; p_i = i_c; p_qx = qcx; p_qy = qcy; p_qz = qcz; p_j = j; p_d = d;
-      sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 = sb4;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(in_q), "+v"(in_b), "+v"(in_i) : : "memory");   // transfers and loads in flight (poll_stop, or past the end)
-    if (pend) found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d, StoreAsm());
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores: the barrier that follows does not know about them
-  };
-  // which search: the pipelined one only in the 256-thread kernels (the LDS addresses of the 1024-thread kernel's staging
-  // region lie beyond the 64 KB an M0 base was checked with)
-  auto org_search_pick = [&](const float r_lim, const bool poll_stop, auto &&found) {
-    if constexpr (FL_ICP_SEARCH == 3 && BS == ICP_BS_SMALL) org_search3(r_lim, poll_stop, found);
-    else if constexpr (FL_ICP_SEARCH >= 2) org_search2(r_lim, poll_stop, found);
-    else org_search(r_lim, poll_stop, found);
-  };
-#define ORG_SEARCH org_search_pick
+  // (Measured in round 3 and not kept, profiles/README.md: the same search software-pipelined over its steps -- the next
+  // step's rectangle fetched by LDS-DMA while this one is scanned -- shortens the search phase by a fifth and lengthens the
+  // chain phases by as much; the rectangle staged as 2-byte depths with the points rebuilt in registers, an eighth of the
+  // staged bytes, is slower still: the conversion sits on the step's critical path.)
+#define ORG_SEARCH org_search
   // the deferred dist_mean chain of the pending distances (chain wave), then -- every wave -- the search for the next iteration
   auto chain_and_search = [&](const int pend, const bool want, const float r_lim, const float old_mean_) {
     if (pend && threadIdx.x < 64) {
@@ -1659,11 +1260,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       }
     }
     if (want)
-      ORG_SEARCH(r_lim, true, [&](bool active, int i, float, float, float, int j, float d, auto &&st) {
+      ORG_SEARCH(r_lim, true, [&](bool active, int i, float, float, float, int j, float d) {
         if (active) {
-          st(nn, i, j);
-          st(nd, i, d);
-          if (j >= 0) st(bnd, i, sqrt_upper(d));          // else: the old partner is still within the old bound
+          nn[i] = j;
+          nd[i] = d;
+          if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
         }
       });
   };
@@ -1737,11 +1338,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
         if (!SPEC)
-          ORG_SEARCH(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d, auto &&st) {
+          ORG_SEARCH(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
             const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
             if (active) {
-              st(nn, i, keep ? j : -1);
-              if (j >= 0) st(bnd, i, sqrt_upper(d));          // else: the old partner is still within the old bound
+              nn[i] = keep ? j : -1;
+              if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
             }
             if (keep) {
               ++kept;
