@@ -198,8 +198,7 @@ def cpu_baseline(args, bank, scenes, K):
     # SURVEY 8(d) also asks for the restatement over all host cores: frames are independent, one per thread
     # (ctypes releases the GIL during the call; the oracle keeps no shared mutable state)
     import concurrent.futures as cf
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, cores)                                                 # every host core this process may run on
+    cores, cores_src = host_cores()
     per_thread = max(1, int(round(n / el * args.cpu_seconds / 2)))       # about cpu_seconds / 2 of work per thread
 
     def work(k):
@@ -212,11 +211,40 @@ def cpu_baseline(args, bank, scenes, K):
         done = sum(ex.map(work, range(cores)))
     el2 = time.perf_counter() - t1
     single["all_cores"] = dict(value=done / el2, unit="frames/s", cores=cores,
-                               sample=f"{done} frames, one frame per thread at a time on all {cores} host cores of this box "
-                                      f"(os.sched_getaffinity), {el2:.1f} s")
+                               sample=f"{done} frames, one frame per thread at a time on all {cores} host cores this process may use "
+                                      f"({cores_src}), {el2:.1f} s")
     single["note"] = ("a scalar port: roughly half of its time is front-end filtering that OpenCV's SIMD kernels do an order of "
                       "magnitude faster, so value / cpu_baseline.value says little about the reference itself")
     return single
+
+
+def host_cores():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where one is set (a
+    one-GPU share of a bigger machine shows all of its cores in the mask but gets only its quota of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    src = f"os.sched_getaffinity: {n}"
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    q = max(1, int(round(int(txt[0]) / int(txt[1]))))
+                    if q < n:
+                        n, src = q, f"cgroup cpu.max {txt[0]}/{txt[1]} of {src}"
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0 and quota // period < n:
+                    n, src = max(1, quota // period), f"cgroup cfs quota {quota}/{period} of {src}"
+            break
+        except Exception:
+            continue
+    env = os.environ.get("FL_BENCH_CPU_THREADS")
+    if env:
+        n, src = max(1, int(env)), "FL_BENCH_CPU_THREADS"
+    if n > 64:                                   # no quota visible on a big shared host: a one-GPU share is 16 cores (task statement)
+        n, src = 16, f"capped: {src}, no cgroup quota visible; one GPU's share of the host is 16 cores"
+    return max(1, n), src
 
 
 def source_digest():

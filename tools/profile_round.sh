@@ -9,14 +9,14 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B=${B:-2560}
+B=${B:-4096}
 T=${T:-2000}
 CMD="python3 bench.py --steps 5 --warmup 2 --batch $B --templates $T --no-cpu-baseline --no-extras"
 out=gpurun_out/prof_final
 rm -rf $out gpurun_out/pmc_final_*
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- $CMD > $out.log 2>&1 || { echo "stats pass failed"; tail -5 $out.log; exit 1; }
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum" "GRBM_GUI_ACTIVE"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum" "GRBM_GUI_ACTIVE" "TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   i=$((i+1))
   timeout -k 10 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_final_$i -- python3 bench.py --steps 2 --warmup 1 --batch $B --templates $T --no-cpu-baseline --no-extras > gpurun_out/pmc_final_$i.log 2>&1 || { echo "pmc group $i failed"; tail -5 gpurun_out/pmc_final_$i.log; exit 1; }
 done
