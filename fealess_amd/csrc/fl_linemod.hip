@@ -284,6 +284,8 @@ int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_strid
 // to a multiple of 8 with the offset of the zero pad so that 8 independent 16-byte loads are in
 // flight per step.  The linear memories (1.2 MB per frame at VGA/T=8) are shared by all
 // templates and are served from L2; the feature tables are the only per-template HBM stream.
+// Between the modalities a wave whose positions can no longer reach the coarse threshold stops (exact: see `prune` in
+// the kernel); the reference adds every feature of every template everywhere (linemod.cpp:1471-1481).
 struct ScanArgs {
   const FlScanHdr *hdr;
   const int2 *items;         // work list: (pyramid, chunk)
@@ -297,6 +299,7 @@ struct ScanArgs {
   int n_pyr, M, nchunks, W, WH, T, cap;
   int bpf, n_frames;         // blocks per frame, frames in this launch
   float threshold;
+  int prune;                 // stop a (template, chunk) between modalities once no position can reach the threshold (exact)
   uint16_t *dbg;             // optional raw u16 maps of pyramids [dbg_first, dbg_first+dbg_count)
   int dbg_first, dbg_count;
 };
@@ -333,9 +336,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
   uint32_t tot[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) tot[i] = 0;
+  // Exact pruning between modalities: a feature adds at most 4 to a position (SIMILARITY_LUT's largest entry), so once the
+  // largest total of this wave's 1024 positions plus 4 x (the features of the modalities still to come) cannot exceed the
+  // coarse threshold, no position of the chunk can become a candidate (`raw > raw_threshold`, linemod.cpp:1490-1492) and the
+  // rest of the template's additions have no observable effect: the wave stops.  The colour modality comes first and is
+  // sparse (gradients only on edges), so on most (template, chunk) pairs the depth modality -- half of the scan's loads -- is
+  // never read.  Not when the raw maps are tapped (fl_similarity_maps), and FL_SCAN_PRUNE=0 switches it off (a.prune).
+  int nf_all = 0;
+  for (int m = 0; m < a.M; ++m) nf_all += a.hdr[g * a.M + m].nf;
+  const int prune_threshold = (int)(2 * nf_all + (a.threshold / 100.f) * (2 * nf_all) + 0.5f);   // = raw_threshold below
+  const bool prune = a.prune && !(a.dbg && g >= a.dbg_first && g < a.dbg_first + a.dbg_count);
   int nf = 0;
   for (int m = 0; m < a.M; ++m) {
     const FlScanHdr h = a.hdr[g * a.M + m];
+    if (prune && m > 0) {
+      uint32_t mx = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = max(mx, tot[i]);
+      if (__ballot((int)mx + 4 * (nf_all - nf) > prune_threshold) == 0ull) return;    // wave-uniform
+    }
     nf += h.nf;
     if (chunk * 1024 >= h.P) continue;                  // wave-uniform; lanes past P load along (masked below): the
                                                        // next lane's first dword is this lane's bytes 16..19
@@ -836,6 +855,7 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.T = g.T;
     a.cap = det->cap;
     a.threshold = threshold;
+    { const char *e = getenv("FL_SCAN_PRUNE"); a.prune = !(e && e[0] == '0'); }
     a.dbg = dbg;
     a.dbg_first = dbg_first;
     a.dbg_count = dbg_count;
