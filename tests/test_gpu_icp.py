@@ -596,3 +596,48 @@ def test_refine_matches_argument_checks_and_result(ctx, oracle):
         det.refine_matches([0], best, sc["K"], params)
     assert ex.value.code == L.FL_ERR_STATE
     det.close()
+
+
+def test_large_batch_jobs_dealt_longest_first_keep_their_results(ctx, oracle, monkeypatch):
+    """A batch above four frames per CU hands the ICP launch its jobs longest first (k_icp_count + k_icp_order: workgroup b
+    runs job order[b]).  The order is scheduling only: every frame's result must be what the same frame gives alone, and what
+    the batch gives in frame order (FL_ICP_ORDER=0), bit for bit -- frames of different cloud sizes, so that the order is a
+    real permutation.  Also the exact pruning of the scan (FL_SCAN_PRUNE=0/1): same matches either way."""
+    import torch
+    scenes = [synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=s, n_views=3) for s in (3, 5)]
+    sc = scenes[0]
+    frames_b, frames_d = [], []
+    for k in range(6):                                       # six distinct frames: two scenes x three shifts (different crops -> cloud sizes)
+        s2 = scenes[k % 2]
+        sh = 14 * (k // 2)
+        frames_b.append(np.roll(s2["bgr"], sh, axis=1))
+        frames_d.append(np.roll(s2["depth"], sh, axis=1))
+    bank = sc["bank"]
+    n = 1100                                                 # > 4 x 256 CUs
+    det = api.Detector(ctx, 2, [5, 8])
+    det.add_class(bank)
+    det.finalize(640, 480, max_batch=n, max_candidates=4096)
+    d_b = torch.from_numpy(np.stack(frames_b)).cuda()
+    d_d = torch.from_numpy(np.stack(frames_d).view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    order = [(7 * i) % 6 for i in range(n)]
+    bp = [d_b.data_ptr() + o * 640 * 480 * 3 for o in order]
+    dp = [d_d.data_ptr() + o * 640 * 480 * 2 for o in order]
+    params = L.RecognitionParams(75.0, 8, 0.0, -3.0e38, L.FL_ICP_PARITY)
+    single = det.recognize_batch(frames_b, frames_d, sc["K"], 75.0, 8, 0.0, -3.0e38)
+    assert sum(r["found"] for r in single) >= 3 and len({r["det"]["n_points"] for r in single if r["found"]}) >= 2
+    runs = {}
+    for tag, env in (("longest_first", {}), ("frame_order", {"FL_ICP_ORDER": "0"}), ("unpruned", {"FL_SCAN_PRUNE": "0"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        det.recognize_submit_device(bp, dp, sc["K"], params)
+        runs[tag] = [api.recognition_result_to_dict(r) for r in det.recognize_collect(n)]
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    for tag, res in runs.items():
+        for i in range(n):
+            e, g = single[order[i]], res[i]
+            assert g["status"] == 0 and g["found"] == e["found"] and g["n_matches"] == e["n_matches"] and g["best"] == e["best"], (tag, i)
+            if e["found"]:
+                assert g["det"]["n_points"] == e["det"]["n_points"] and np.array_equal(_bits(g["pose"]), _bits(e["pose"])), (tag, i)
+    det.close()
