@@ -300,11 +300,19 @@ struct ScanArgs {
   int bpf, n_frames;         // blocks per frame, frames in this launch
   float threshold;
   int prune;                 // stop a (template, chunk) between modalities once no position can reach the threshold (exact)
+  unsigned prune_mid;        // ... and inside a modality after the 8-feature groups whose bit is set (same bound, same exactness)
   uint16_t *dbg;             // optional raw u16 maps of pyramids [dbg_first, dbg_first+dbg_count)
   int dbg_first, dbg_count;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// the larger even byte and the larger odd byte of a word, as two 16-bit values (v_pk_max_u16)
+__device__ __forceinline__ u16x2 pk_bytes_max(uint32_t a)
+{
+  const uint32_t lo = a & 0x00FF00FFu, hi = (a >> 8) & 0x00FF00FFu;
+  return __builtin_elementwise_max(__builtin_bit_cast(u16x2, lo), __builtin_bit_cast(u16x2, hi));
+}
 __device__ __forceinline__ uint4 ld16(const uint8_t *p)
 {
   uint4 v;
@@ -312,6 +320,10 @@ __device__ __forceinline__ uint4 ld16(const uint8_t *p)
   return v;
 }
 
+#ifndef FL_SCAN_PRUNE_MID
+#define FL_SCAN_PRUNE_MID 0x7Fu   // 8-feature groups after which a modality checks the bound (every one but the last: the check
+                                  // after 16 features is the one that pays -- chunks without colour edges stop there)
+#endif
 #ifndef FL_SCAN_WPE
 #define FL_SCAN_WPE 5             // waves per SIMD; measured after the DPP change (ms per 1280 frames x 360 templates): 3: 2.32, 4: 1.95, 5: 1.71, 6: 1.77, 8: 2.17
 #endif
@@ -349,12 +361,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
   int nf = 0;
   for (int m = 0; m < a.M; ++m) {
     const FlScanHdr h = a.hdr[g * a.M + m];
+    uint32_t mx_tot = 0;                                 // the lane's largest total of the modalities done
     if (prune && m > 0) {
-      uint32_t mx = 0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) mx = max(mx, tot[i]);
-      if (__ballot((int)mx + 4 * (nf_all - nf) > prune_threshold) == 0ull) return;    // wave-uniform
+      for (int i = 0; i < 16; ++i) mx_tot = max(mx_tot, tot[i]);
+      if (__ballot((int)mx_tot + 4 * (nf_all - nf) > prune_threshold) == 0ull) return;    // wave-uniform
     }
+    const unsigned mid = prune ? a.prune_mid : 0u;
     nf += h.nf;
     if (chunk * 1024 >= h.P) continue;                  // wave-uniform; lanes past P load along (masked below): the
                                                        // next lane's first dword is this lane's bytes 16..19
@@ -376,6 +389,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
     // not a select per load (measured in round 1: that serialised the eight loads in flight) -- and the masked lanes' loads
     // are simply not issued: 19 % less L2 traffic.
     const int lanes_on = min(64, ((h.P - chunk * 1024 + 15) >> 4) + 1);
+    bool dead = false;
     if (lane < lanes_on)
     for (int k = 0; k < h.n_pad; k += 8) {
       uint4 v[8];
@@ -400,7 +414,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
         a2 += __builtin_amdgcn_alignbyte(v[u].w, v[u].z, mis[u]);
         a3 += __builtin_amdgcn_alignbyte(e[u], v[u].w, mis[u]);
       }
+      if ((mid >> (k >> 3)) & 1u) {                      // wave-uniform
+        // the same bound inside the modality: the lane's largest byte so far on top of its largest finished total
+        // (an over-estimate of its largest partial total, so nothing reachable is ever dropped)
+        const u16x2 b0 = pk_bytes_max(a0), b1 = pk_bytes_max(a1), b2 = pk_bytes_max(a2), b3 = pk_bytes_max(a3);
+        const u16x2 bm = __builtin_elementwise_max(__builtin_elementwise_max(b0, b1), __builtin_elementwise_max(b2, b3));
+        const int part = (int)max(bm.x, bm.y);
+        const int left = nf_all - nf + max(0, h.nf - (k + 8));
+        if (__ballot((int)mx_tot + part + 4 * left > prune_threshold) == 0ull) { dead = true; break; }
+      }
     }
+    if (__ballot(dead) != 0ull) return;                 // lanes outside lanes_on follow (they have nothing to add)
     const uint32_t acc[4] = {a0, a1, a2, a3};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -856,6 +880,7 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.cap = det->cap;
     a.threshold = threshold;
     { const char *e = getenv("FL_SCAN_PRUNE"); a.prune = !(e && e[0] == '0'); }
+    { const char *e = getenv("FL_SCAN_PRUNE_MID"); a.prune_mid = e ? (unsigned)strtoul(e, nullptr, 16) : FL_SCAN_PRUNE_MID; }
     a.dbg = dbg;
     a.dbg_first = dbg_first;
     a.dbg_count = dbg_count;

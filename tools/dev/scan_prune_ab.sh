@@ -1,6 +1,8 @@
 #!/bin/bash
-# dev only: k_scan with and without the exact pruning between modalities (FL_SCAN_PRUNE=0/1, same library), one box
+# dev only: k_scan's exact pruning, one box: off / between modalities only / with checks inside a modality
+# (FL_SCAN_PRUNE=0|1, FL_SCAN_PRUNE_MID=<hex mask of the 8-feature groups after which the bound is checked>)
 cd "$GRAFT_REPO_ROOT"
 run() { timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --templates 2000 --batch ${B:-2048} $1 2>&1 | grep -o "\"value[^,]*\|\"scan_ms[^,]*\|\"ms_per_step[^,]*" | tr '\n' ' '; echo; }
-for P in 0 1 0 1; do echo -n "[prune=$P c2 b${B:-2048}] "; FL_SCAN_PRUNE=$P run ""; done
-for P in 0 1; do echo -n "[prune=$P c3] "; FL_SCAN_PRUNE=$P B=256 run "--config c3"; done
+echo -n "[prune=0 c2 b${B:-2048}] "; FL_SCAN_PRUNE=0 run ""
+for M in ${MASKS:-0 68 0 68 28 7e 08 40}; do echo -n "[mid=$M c2 b${B:-2048}] "; FL_SCAN_PRUNE_MID=$M run ""; done
+for M in 0 68; do echo -n "[mid=$M c3] "; FL_SCAN_PRUNE_MID=$M B=256 run "--config c3"; done
