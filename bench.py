@@ -440,9 +440,11 @@ def main():
         hs = np.array([[0.0] * 5 + list(r.pose)[5:] + list(r.det.R_final) + list(r.det.T_final) for r in res]).sum(0)
         stt = hs[11:16].copy() / len(res) / 4e6              # per wave (4 waves per workgroup), M cycles
         hs[11:16] = 0
-        a2 = hs[22:25].copy() / len(res) / 1e6
+        a2 = hs[22:25].copy() * 16 / len(res) / 1e6
         hs[22:25] = 0
         print("icp phase A2, M cycles per workgroup: chain wave adding %.2f, chain wave at the tile barrier %.2f, a producer wave at the tile barrier %.2f" % tuple(a2), file=sys.stderr)
+        print("icp phase B, M cycles per workgroup: chain wave adding %.2f, chain wave at the tile barrier %.2f, a producer wave at the tile barrier %.2f" % tuple(hs[25:28] * 16 / len(res) / 1e6), file=sys.stderr)
+        hs[25:28] = 0
         print("icp search step segments, M cycles per wave: wait for the query %.2f, window + reductions %.2f, staging %.2f, scan %.2f, "
               "epilogue + stores %.2f" % tuple(stt), file=sys.stderr)
         tot = max(hs[:16].sum(), 1)

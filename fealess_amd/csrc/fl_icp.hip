@@ -50,8 +50,18 @@
 #define ICP_DT 512                 // terms per block of the deferred dist_mean chain (two float4 per lane of the chain wave)
 #ifdef FL_ICP_PHASES
 #define TSTAMP(k) do { if (threadIdx.x == 0) { long long now_ = clock64(); S.tacc[k] += now_ - S.tlast; S.tlast = now_; } } while (0)
+// chain phases: what the chain wave spends adding and at the tile barrier (S.hist[k], [k + 1]), and what the first producer
+// wave spends at the tile barriers (S.hist[k]; one barrier in `every` is timed); units of 16 cycles
+#define CH_STAMP_BEGIN long long c_add = 0, c_bar = 0, c_last = clock64()
+#define CH_STAMP(v) { const long long now_ = clock64(); v += now_ - c_last; c_last = now_; }
+#define CH_STAMP_END(k) { if (threadIdx.x == 0) { S.hist[k] += (unsigned)(c_add >> 4); S.hist[(k) + 1] += (unsigned)(c_bar >> 4); } }
+#define PR_STAMP_BARRIER(k, every) { const long long b0_ = clock64(); tile_barrier(); if (threadIdx.x == 64) S.hist[k] += (unsigned)(((clock64() - b0_) * (every)) >> 4); }
 #else
 #define TSTAMP(k) do { } while (0)
+#define CH_STAMP_BEGIN
+#define CH_STAMP(v) { }
+#define CH_STAMP_END(k) { }
+#define PR_STAMP_BARRIER(k, every) tile_barrier()
 #endif
 #ifndef FL_ICP_WPE
 #define FL_ICP_WPE 4               // waves per SIMD the default 256-thread recognition kernel is compiled for (4 -> 128 VGPRs, 5 -> 96; a
@@ -917,17 +927,21 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   const bool chain_wave = parity && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
   if (chain_wave) {
     // the chain wave's own loop (see the A2 phase): one barrier per tile like the producers' below
+    CH_STAMP_BEGIN;
     for (int t = 0; t < ntiles; ++t) {
       if (t > 0 && threadIdx.x == 0) acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
+      CH_STAMP(c_add);
       tile_barrier();
+      CH_STAMP(c_bar);
     }
+    CH_STAMP_END(26);
   } else if (slot >= 0) {
     Row A, B;
     if (ntiles > 0) row_load(A, 0);
     for (int t = 0; t < ntiles; t += 2) {
       row_load(B, t + 1);
       row_process(A, t);
-      tile_barrier();
+      PR_STAMP_BARRIER(28, 2);
       if (t + 1 < ntiles) {
         row_load(A, t + 2);
         row_process(B, t + 1);
@@ -1154,8 +1168,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           if (S.iter <= 3) atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)(4 * nbw * maxh));
           const int wcl = W <= 13 ? 0 : (W <= 29 ? 1 : (W <= 61 ? 2 : 3)), hcl = H <= 5 ? 0 : (H <= 10 ? 1 : (H <= 20 ? 2 : 3));
           atomicAdd(&S.hist[wcl * 4 + hcl], 1u);
-          atomicAdd(&S.hist[16 + min(maxh, 10) - 1], 1u);
-          atomicAdd(&S.hist[26 + min(nbw, 4) - 1], 1u);
+          atomicAdd(&S.hist[16 + min(maxh, 6) - 1], 1u);   // (bins 22..24 and 26..28 carry the chain phases' stamps)
         }
 #endif
         unsigned long long best = NN_KEY_NONE;
@@ -1431,11 +1444,15 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const bool chain_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
       if (chain_wave) {
         // the chain wave's own loop: one barrier per tile like the producers' below
+        CH_STAMP_BEGIN;
         for (int t = 0; t < ntiles; ++t) {
           if (t > 0 && threadIdx.x < 15)
             acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+          CH_STAMP(c_add);
           tile_barrier();
+          CH_STAMP(c_bar);
         }
+        CH_STAMP_END(22);
       } else if (slot >= 0) {
         Row X, Y, Z;
         row_load(X, 0);
@@ -1443,7 +1460,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         row_gather(X);
         for (int t = 0; t < ntiles; t += 3) {
           row_load(Z, t + 2); row_gather(Y); row_write(X, t);
-          tile_barrier();
+          PR_STAMP_BARRIER(24, 3);
           if (t + 1 < ntiles) {
             row_load(X, t + 3); row_gather(Z); row_write(Y, t + 1);
             tile_barrier();

@@ -21,6 +21,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   timeout -k 10 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_final_$i -- python3 bench.py --steps 2 --warmup 1 --batch $B --templates $T --no-cpu-baseline --no-extras > gpurun_out/pmc_final_$i.log 2>&1 || { echo "pmc group $i failed"; tail -5 gpurun_out/pmc_final_$i.log; exit 1; }
 done
 python3 -c "import bench; print(bench.source_digest())" > gpurun_out/pmc_src_digest.txt
+python3 tools/profile_summarise.py ${TAG:-r03} $B $T --pmc-only || exit 1      # the bench lines below quote `traffic` from it
 timeout -k 10 900 python3 bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err || { echo "bench failed"; tail -5 gpurun_out/bench_final.err; exit 1; }
 timeout -k 10 500 python3 bench.py --config c3 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err || { echo "bench c3 failed"; tail -5 gpurun_out/bench_c3.err; exit 1; }
 tail -c 600 gpurun_out/bench_final.json

@@ -3,7 +3,9 @@ profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json (stamped with the diges
 collected on: bench.py quotes `traffic` from it only while that digest matches), profiles/<tag>_bench.json,
 profiles/<tag>_bench_c3.json.
 
-usage: python tools/profile_summarise.py r02 [batch] [templates]
+usage: python tools/profile_summarise.py r02 [batch] [templates] [--pmc-only]
+(--pmc-only: just the PMC digest -- tools/profile_round.sh calls it on the GPU box in front of the final bench runs, so
+that their `roofline.traffic` is quoted from the counters collected minutes earlier on the same sources)
 """
 import collections
 import csv
@@ -14,9 +16,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
-templates = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+pmc_only = "--pmc-only" in sys.argv
+argv = [a for a in sys.argv if a != "--pmc-only"]
+tag = argv[1]
+batch = int(argv[2]) if len(argv) > 2 else 1280
+templates = int(argv[3]) if len(argv) > 3 else 2000
 out = os.path.join(ROOT, "profiles")
 src = os.path.join(ROOT, "gpurun_out")
 
@@ -46,6 +50,9 @@ json.dump({
             "coalesced reads by up to 2x -- MI355X_MICROARCH.md); SQ_* cycle counters are quad-cycles summed over waves; "
             "separate passes per counter group (tools/profile_round.sh)",
     "batch": batch, "templates": templates, "kernels": kernels}, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+if pmc_only:
+    print("wrote", f"{tag}_pmc.json")
+    sys.exit(0)
 line = [l for l in open(os.path.join(src, "bench_final.json")) if l.startswith("{")][-1]
 open(os.path.join(out, f"{tag}_bench.json"), "w").write(line)
 if os.path.exists(os.path.join(src, "bench_c3.json")):
