@@ -504,6 +504,12 @@ def pmc_traffic(args, bank, kernel):
                       source=os.path.relpath(PMC_FILE, ROOT), src_digest=pm["src_digest"],
                       note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB units); gfx950 FETCH_SIZE "
                            "under-counts wide coalesced reads by up to 2x, so true HBM reads lie between 1x and 2x fetch_bytes")
+        if "SQ_ACTIVE_INST_VALU" in kd and kd.get("GRBM_GUI_ACTIVE"):
+            # SQ_ACTIVE_INST_VALU counts in units of 4 cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            simd_cycles = kd["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4
+            detail["valu_busy"] = round(4.0 * kd["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3)
+            detail["valu_note"] = ("fraction of the launch the SIMDs spend issuing vector ALU instructions (4 cycles per wave64 "
+                                   "instruction): what bounds this kernel next to its two sequential chains, see DESIGN.md section 4")
         return (kd["FETCH_SIZE"] + kd["WRITE_SIZE"]) * 1024.0, detail
     except Exception:
         return None, None
