@@ -509,7 +509,8 @@ def pmc_traffic(args, bank, kernel):
             simd_cycles = kd["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4
             detail["valu_busy"] = round(4.0 * kd["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3)
             detail["valu_note"] = ("fraction of the launch the SIMDs spend issuing vector ALU instructions (4 cycles per wave64 "
-                                   "instruction): what bounds this kernel next to its two sequential chains, see DESIGN.md section 4")
+                                   "instruction); high, but not the binding resource by itself (5 % fewer vector instructions "
+                                   "measured the same): DESIGN.md section 4, profiles/README.md")
         return (kd["FETCH_SIZE"] + kd["WRITE_SIZE"]) * 1024.0, detail
     except Exception:
         return None, None
