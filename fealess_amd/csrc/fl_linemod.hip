@@ -389,9 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
     // not a select per load (measured in round 1: that serialised the eight loads in flight) -- and the masked lanes' loads
     // are simply not issued: 19 % less L2 traffic.
     const int lanes_on = min(64, ((h.P - chunk * 1024 + 15) >> 4) + 1);
-    bool dead = false;
-    if (lane < lanes_on)
+    const bool on = lane < lanes_on;
     for (int k = 0; k < h.n_pad; k += 8) {
+      if (on) {
       uint4 v[8];
       uint32_t e[8];
       unsigned mis[8];
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
         a2 += __builtin_amdgcn_alignbyte(v[u].w, v[u].z, mis[u]);
         a3 += __builtin_amdgcn_alignbyte(e[u], v[u].w, mis[u]);
       }
+      }
       if ((mid >> (k >> 3)) & 1u) {                      // wave-uniform
         // the same bound inside the modality: the lane's largest byte so far on top of its largest finished total
         // (an over-estimate of its largest partial total, so nothing reachable is ever dropped)
@@ -421,10 +422,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
         const u16x2 bm = __builtin_elementwise_max(__builtin_elementwise_max(b0, b1), __builtin_elementwise_max(b2, b3));
         const int part = (int)max(bm.x, bm.y);
         const int left = nf_all - nf + max(0, h.nf - (k + 8));
-        if (__ballot((int)mx_tot + part + 4 * left > prune_threshold) == 0ull) { dead = true; break; }
+        // (every lane votes: one past this modality's template_positions adds nothing here, its bound is simply generous --
+        // it may still collect from a modality whose template_positions reach further)
+        if (__ballot((int)mx_tot + part + 4 * left > prune_threshold) == 0ull) return;          // wave-uniform
       }
     }
-    if (__ballot(dead) != 0ull) return;                 // lanes outside lanes_on follow (they have nothing to add)
     const uint32_t acc[4] = {a0, a1, a2, a3};
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
