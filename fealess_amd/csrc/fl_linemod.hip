@@ -218,7 +218,9 @@ int fl_launch_spread_tiles(fl_context *ctx, const uint8_t *quant, size_t quant_s
 {
   const bool aligned = ((uintptr_t)quant % 4 == 0) && (quant_stride % 4 == 0) && ((uintptr_t)spread % 4 == 0) && (spread_stride % 4 == 0);
   if (w % 4 == 0 && T <= 8 && T >= 2 && aligned) {
-    int k = 4;
+    int k = 6;                                   // strips of k x T rows: the taller, the longer the runs a strip writes into each linear
+                                                 // memory (k * W bytes); measured at VGA level 1, ms per 2048 frames, k = 2 / 3 / 4 / 6 / 8:
+                                                 // 1.49 / 1.37 / 1.30 - 1.35 / 1.18 / 1.16 - 1.20
     size_t lds;
     for (;;) {
       lds = (size_t)2 * (k * T + T - 1) * (w + 16);
@@ -253,7 +255,9 @@ int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_strid
   const uint32_t stride = (uint32_t)fl_lm_label_stride(w, h, T);
   const bool aligned = ((uintptr_t)quant % 4 == 0) && (quant_stride % 4 == 0) && ((uintptr_t)lm % 4 == 0) && (lm_stride % 4 == 0);
   if (w % 4 == 0 && W % 4 == 0 && T <= 8 && T >= 2 && aligned) {
-    int k = 4;
+    int k = 6;                                   // strips of k x T rows: the taller, the longer the runs a strip writes into each linear
+                                                 // memory (k * W bytes); measured at VGA level 1, ms per 2048 frames, k = 2 / 3 / 4 / 6 / 8:
+                                                 // 1.49 / 1.37 / 1.30 - 1.35 / 1.18 / 1.16 - 1.20
     size_t lds;
     for (;;) {
       lds = (size_t)2 * (k * T + T - 1) * (w + 16) + 2048;
@@ -284,8 +288,8 @@ int fl_launch_build_lm(fl_context *ctx, const uint8_t *quant, size_t quant_strid
 // to a multiple of 8 with the offset of the zero pad so that 8 independent 16-byte loads are in
 // flight per step.  The linear memories (1.2 MB per frame at VGA/T=8) are shared by all
 // templates and are served from L2; the feature tables are the only per-template HBM stream.
-// Between the modalities a wave whose positions can no longer reach the coarse threshold stops (exact: see `prune` in
-// the kernel); the reference adds every feature of every template everywhere (linemod.cpp:1471-1481).
+// Between the modalities and after every 8 features a wave whose positions can no longer reach the coarse threshold stops
+// (exact: see `prune` in the kernel); the reference adds every feature of every template everywhere (linemod.cpp:1471-1481).
 struct ScanArgs {
   const FlScanHdr *hdr;
   const int2 *items;         // work list: (pyramid, chunk)
@@ -353,7 +357,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
   // coarse threshold, no position of the chunk can become a candidate (`raw > raw_threshold`, linemod.cpp:1490-1492) and the
   // rest of the template's additions have no observable effect: the wave stops.  The colour modality comes first and is
   // sparse (gradients only on edges), so on most (template, chunk) pairs the depth modality -- half of the scan's loads -- is
-  // never read.  Not when the raw maps are tapped (fl_similarity_maps), and FL_SCAN_PRUNE=0 switches it off (a.prune).
+  // never read.  The same bound is checked inside a modality after the 8-feature groups a.prune_mid names (chunks without
+  // colour edges stop after 16 features).  Not when the raw maps are tapped (fl_similarity_maps), and FL_SCAN_PRUNE=0
+  // switches it off (a.prune).
   int nf_all = 0;
   for (int m = 0; m < a.M; ++m) nf_all += a.hdr[g * a.M + m].nf;
   const int prune_threshold = (int)(2 * nf_all + (a.threshold / 100.f) * (2 * nf_all) + 0.5f);   // = raw_threshold below
