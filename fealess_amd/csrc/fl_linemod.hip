@@ -218,9 +218,8 @@ int fl_launch_spread_tiles(fl_context *ctx, const uint8_t *quant, size_t quant_s
 {
   const bool aligned = ((uintptr_t)quant % 4 == 0) && (quant_stride % 4 == 0) && ((uintptr_t)spread % 4 == 0) && (spread_stride % 4 == 0);
   if (w % 4 == 0 && T <= 8 && T >= 2 && aligned) {
-    int k = 6;                                   // strips of k x T rows: the taller, the longer the runs a strip writes into each linear
-                                                 // memory (k * W bytes); measured at VGA level 1, ms per 2048 frames, k = 2 / 3 / 4 / 6 / 8:
-                                                 // 1.49 / 1.37 / 1.30 - 1.35 / 1.18 / 1.16 - 1.20
+    int k = 4;                                   // strips of k x T rows (taller strips cost the lazy fine level more than they save:
+                                                 // k = 6 took 5.0 against 3.95 ms per 4096 frames, a strip works for every marked tile it touches)
     size_t lds;
     for (;;) {
       lds = (size_t)2 * (k * T + T - 1) * (w + 16);
