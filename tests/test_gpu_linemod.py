@@ -145,6 +145,39 @@ def test_quirks_overread_oob_and_big_template(ctx, oracle):
     det.close()
 
 
+def test_pruned_scan_when_the_modalities_templates_differ_in_size(ctx, oracle, monkeypatch):
+    """k_scan stops a (template, chunk) once no position can reach the threshold.  The positions a modality scans end at ITS
+    template_positions (linemod.cpp:1152-1160), so with a small colour template and a large depth template there are positions
+    that collect from the colour modality alone -- here they are the only candidates, every position the depth modality
+    scans is hopeless, and the wave must not stop on their account.  Thresholds from -100 % to 100 %, with and without pruning."""
+    rng = np.random.default_rng(77)
+    w0, h0, T = 320, 240, [8]
+    q0 = np.zeros((h0, w0), np.uint8)
+    q0[184:, :] = (1 << rng.integers(0, 8, (h0 - 184, w0))).astype(np.uint8)   # colour labels only in the lowest rows
+    qs = [q0, np.zeros((h0, w0), np.uint8)]                                    # no depth labels at all
+    f0 = np.stack([rng.integers(0, 40, 12), rng.integers(0, 40, 12), rng.integers(0, 8, 12)], 1).astype(np.int32)
+    f1 = np.stack([rng.integers(0, 200, 4), rng.integers(0, 100, 4), rng.integers(0, 8, 4)], 1).astype(np.int32)
+    bank = _one_template_bank(1, 2, [dict(width=40, height=40, offset_x=0, offset_y=0, features=f0),      # 1036 positions
+                                     dict(width=200, height=100, offset_x=0, offset_y=0, features=f1)])   # 696 positions
+    det = api.Detector(ctx, 2, T)
+    det.add_class(bank)
+    det.finalize(w0, h0)
+    seen = 0
+    for thr in (-100.0, 0.0, 20.0, 45.0, 60.0, 100.0):
+        exp, n_exp = oracle.match_quantized(qs, w0, h0, T, [bank], thr)
+        for prune in ("1", "0"):
+            monkeypatch.setenv("FL_SCAN_PRUNE", prune)
+            got, n_got = det.match_quantized(qs, thr, cap=1 << 16)
+            assert n_got == n_exp, (thr, prune)
+            _assert_matches_equal(got, exp)
+        seen += n_exp
+        if thr == 20.0:
+            cell = ((exp["y"] - 3) // 8) * 40 + (exp["x"] - 3) // 8     # matchClass: x = c * T + T / 2 - 1
+            assert n_exp > 0 and np.all(cell >= 696)             # every match lies beyond the depth template's positions
+    assert seen > 0
+    det.close()
+
+
 def test_empty_bank_and_no_match(ctx, oracle):
     rng = np.random.default_rng(2)
     qs = _quant_pyramid(rng, 320, 240, 2, 2)
