@@ -292,40 +292,61 @@ __global__ __launch_bounds__(256) void k_pyrdown_general(const uint8_t *__restri
   pyrdown_general_px(src, w, h, x, y, dst + ((size_t)y * dw + x) * 3);
 }
 
+// A wave owns 64 pairs of adjacent output pixels and walks PD_ROWS output rows down: output row y reads source rows
+// 2y - 2 .. 2y + 2 and shares three of them with row y + 1, so the horizontal sums of a source row (six per lane: two pixels x
+// three channels) are formed once and kept in a five-row register ring that trades roles by unrolling (two new source rows
+// per output row instead of five, 140 vector instructions per output row instead of 312; measured: front-end 4.96 -> 4.87 ms
+// per 2048 VGA frames).
+#define PD_ROWS 8
 __global__ __launch_bounds__(256) void k_pyrdown_pairs(const uint8_t *__restrict__ src_, size_t in_stride,
                                                        uint8_t *__restrict__ dst_, size_t out_stride, int w, int h)
 {
   const int dw = w / 2, dh = h / 2;
-  const int xp = blockIdx.x * 32 + (threadIdx.x & 31) + 1, y = blockIdx.y * 8 + (threadIdx.x >> 5);   // pair index >= 1
-  if (xp > dw / 2 - 2 || y >= dh) return;                 // the last pair (and an odd last pixel) belong to the border grid
+  const int xp = blockIdx.x * 64 + (threadIdx.x & 63) + 1;                    // pair index >= 1
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
+  if (xp > dw / 2 - 2 || y0 >= dh) return;                // the last pair (and an odd last pixel) belong to the border grid
   const uint8_t *src = src_ + (size_t)blockIdx.z * in_stride;
   uint8_t *dst = dst_ + (size_t)blockIdx.z * out_stride;
-  const int k[5] = {1, 4, 6, 4, 1};
-  int acc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    const int yy = reflect101(2 * y + j - 2, h);
-    uint32_t wd[6];                                       // bytes 12 xp - 8 .. 12 xp + 15; source pixel 4 xp - 2 + t at byte 2 + 3 t
+  // horizontal [1 4 6 4 1] sums of one source row for this lane's two output pixels (taps 0..4 and 2..6 of the seven source
+  // pixels 4 xp - 2 .. 4 xp + 4; bytes 12 xp - 8 .. 12 xp + 15 hold them from byte 2 on)
+  auto hrow = [&](int r, int (&o)[6]) {
+    const int yy = reflect101(r, h);
+    uint32_t wd[6];
     const uint8_t *p = src + (size_t)yy * w * 3 + 12 * xp - 8;
     __builtin_memcpy(wd, p, 16);
     __builtin_memcpy(wd + 4, p + 16, 8);
 #define SB(b) ((int)((wd[(b) >> 2] >> (8 * ((b) & 3))) & 0xFFu))
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const int r0 = SB(2 + ch) + 4 * SB(5 + ch) + 6 * SB(8 + ch) + 4 * SB(11 + ch) + SB(14 + ch);        // taps t = 0..4
-      const int r1 = SB(8 + ch) + 4 * SB(11 + ch) + 6 * SB(14 + ch) + 4 * SB(17 + ch) + SB(20 + ch);      // taps t = 2..6
-      acc[ch] += k[j] * r0;
-      acc[3 + ch] += k[j] * r1;
+      o[ch] = SB(2 + ch) + 4 * SB(5 + ch) + 6 * SB(8 + ch) + 4 * SB(11 + ch) + SB(14 + ch);
+      o[3 + ch] = SB(8 + ch) + 4 * SB(11 + ch) + 6 * SB(14 + ch) + 4 * SB(17 + ch) + SB(20 + ch);
     }
 #undef SB
-  }
-  uint16_t *o = (uint16_t *)(dst + ((size_t)y * dw + 2 * xp) * 3);         // 6 bytes at an even offset
-  uint32_t v[6];
+  };
+  int H[5][6];                                            // ring: source rows 2y - 2 .. 2y + 2 of the current output row
+  hrow(2 * y0 - 2, H[0]);
+  hrow(2 * y0 - 1, H[1]);
+  hrow(2 * y0, H[2]);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) v[c] = (uint32_t)((acc[c] + 128) >> 8);
-  o[0] = (uint16_t)(v[0] | (v[1] << 8));
-  o[1] = (uint16_t)(v[2] | (v[3] << 8));
-  o[2] = (uint16_t)(v[4] | (v[5] << 8));
+  for (int k = 0; k < PD_ROWS; ++k) {
+    const int y = y0 + k;
+    if (y < dh) {                                          // wave-uniform
+      // slots (2k + j) % 5 hold source row 2y - 2 + j
+      hrow(2 * y + 1, H[(2 * k + 3) % 5]);
+      hrow(2 * y + 2, H[(2 * k + 4) % 5]);
+      uint32_t v[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int acc = H[(2 * k) % 5][c] + 4 * H[(2 * k + 1) % 5][c] + 6 * H[(2 * k + 2) % 5][c] + 4 * H[(2 * k + 3) % 5][c] +
+                        H[(2 * k + 4) % 5][c];
+        v[c] = (uint32_t)((acc + 128) >> 8);
+      }
+      uint16_t *o = (uint16_t *)(dst + ((size_t)y * dw + 2 * xp) * 3);         // 6 bytes at an even offset
+      o[0] = (uint16_t)(v[0] | (v[1] << 8));
+      o[1] = (uint16_t)(v[2] | (v[3] << 8));
+      o[2] = (uint16_t)(v[4] | (v[5] << 8));
+    }
+  }
 }
 
 int fl_launch_pyrdown_bgr(fl_context *ctx, const uint8_t *src, size_t in_stride, uint8_t *dst, size_t out_stride,
@@ -338,7 +359,7 @@ int fl_launch_pyrdown_bgr(fl_context *ctx, const uint8_t *src, size_t in_stride,
     dim3 grid((dw + 31) / 32, (dh + 7) / 8, n_frames);
     hipLaunchKernelGGL(k_pyrdown_general, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h, 0);
   } else {
-    dim3 grid((dw / 2 - 2 + 31) / 32, (dh + 7) / 8, n_frames);             // pairs 1 .. dw/2 - 2
+    dim3 grid((dw / 2 - 2 + 63) / 64, (dh + 4 * PD_ROWS - 1) / (4 * PD_ROWS), n_frames);             // pairs 1 .. dw/2 - 2
     hipLaunchKernelGGL(k_pyrdown_pairs, grid, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h);
     dim3 gridb((4 * dh + 255) / 256, 1, n_frames);
     hipLaunchKernelGGL(k_pyrdown_general, gridb, dim3(256), 0, ctx->stream, src, in_stride, dst, out_stride, w, h, 1);
