@@ -25,9 +25,10 @@ out = os.path.join(ROOT, "profiles")
 src = os.path.join(ROOT, "gpurun_out")
 
 # gpurun merges every call's output into gpurun_out/, so older runs may still be there: take the newest file only
-stats = sorted(glob.glob(os.path.join(src, "prof_final", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
-assert stats, "no kernel_stats.csv under gpurun_out/prof_final"
-shutil.copy(stats[-1], os.path.join(out, f"{tag}_kernel_stats.csv"))
+if not pmc_only:
+    stats = sorted(glob.glob(os.path.join(src, "prof_final", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    assert stats, "no kernel_stats.csv under gpurun_out/prof_final"
+    shutil.copy(stats[-1], os.path.join(out, f"{tag}_kernel_stats.csv"))
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
