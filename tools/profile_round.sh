@@ -39,4 +39,5 @@ python3 -c "import bench; print(bench.source_digest())" > gpurun_out/pmc_src_dig
 python3 tools/profile_summarise.py ${TAG:-r03} $B $T --pmc-only || exit 1
 }
 for part in ${MODE:-stats bench pmc}; do do_$part || exit 1; done
-[ -f gpurun_out/bench_final.json ] && tail -c 600 gpurun_out/bench_final.json
+if [ -f gpurun_out/bench_final.json ]; then tail -c 600 gpurun_out/bench_final.json; fi
+exit 0
