@@ -489,6 +489,13 @@ __device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
   return v;
 }
 
+// bnd[] is only ever an UPPER bound (a wider search radius visits more pixels, the neighbour found is the same), so it is kept
+// as the top 16 bits of its float32 pattern, rounded UP: 8 of the ~155 bytes the kernel moves per point and iteration.
+// (+inf and NaN stay what they are: both mean "no bound".)
+typedef uint16_t bnd_t;
+__device__ __forceinline__ float bnd_ld(const bnd_t *__restrict__ b, int i) { return __uint_as_float((unsigned)ld_u32(b, i) << 16); }
+__device__ __forceinline__ void bnd_st(bnd_t *b, int i, float v) { b[i] = (bnd_t)((__float_as_uint(v) + 0xFFFFu) >> 16); }
+
 // An UPPER bound of sqrt(x) for the search-radius bookkeeping (bnd[]): the hardware's 1-ulp v_sqrt_f32 inflated past
 // its error (and past a flushed denormal) instead of the ~15-instruction correctly rounded sqrtf.  Any over-estimate
 // only widens the visited area; the nearest neighbour found is the same.
@@ -855,7 +862,7 @@ __device__ __forceinline__ unsigned long long org_scan(F fetch, int RS, int ou, 
 // every thread produces, the valid / inlier counts are left in S.cnt / S.inl, and the chain wave adds the terms later
 // (chain_deferred) while the other waves already search for the next iteration.
 template <int MODE, bool DEFER, class SH>
-__device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *ref, float *bnd, float *dterm, int n, float thr,
+__device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *ref, bnd_t *bnd, float *dterm, int n, float thr,
                                              const float *Ropt, const float *Topt)
 {
   constexpr bool parity = MODE == FL_ICP_PARITY && !DEFER;   // chains in this phase
@@ -876,7 +883,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
     const int i = min(t * TQ + slot, n - 1);              // clamped: unused past the end
     w.a = ld3_u32(mod, i);
     w.b = ld3_u32(ref, i);
-    w.bnd = Ropt ? ld_u32(bnd, i) : 0.0f;
+    w.bnd = Ropt ? bnd_ld(bnd, i) : 0.0f;
   };
   auto row_process = [&](const Row &w, int t) {
     const int i = t * TQ + slot;
@@ -901,11 +908,11 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
           mod[3 * i + 1] = a[1];
           mod[3 * i + 2] = a[2];
         }
-        bnd[i] = w.bnd + move;                            // triangle inequality: still reaches the old partner
+        bnd_st(bnd, i, w.bnd + move);                     // triangle inequality: still reaches the old partner
       } else {
         // first bound: the index pair (n_ref >= n_model); NaN/inf simply disable the bound
         const float ex = a[0] - b0, ey = a[1] - b1, ez = a[2] - b2;
-        bnd[i] = sqrt_upper(ex * ex + ey * ey + ez * ez);
+        bnd_st(bnd, i, sqrt_upper(ex * ex + ey * ey + ez * ez));
       }
       if (vvalid(b2) && vvalid(a[2])) {
         const float dx = a[0] - b0, dy = a[1] - b1, dz = a[2] - b2;
@@ -1001,7 +1008,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
   float4 *sref = (float4 *)(wsb + L.sref);
   int *nn = (int *)(wsb + L.nn);
-  float *bnd = (float *)(wsb + L.bnd);
+  bnd_t *bnd = (bnd_t *)(wsb + L.bnd);
   float *nd = (float *)(wsb + L.nd), *dterm = (float *)(wsb + L.dterm);
   const int *perm = (const int *)(wsb + L.perm);
   const float *nrm = (const float *)(wsb + L.nrm);
@@ -1103,7 +1110,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     int i_n = ld_u32(perm, min(sb1 + lane, last_s));
     int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
     F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
-    float b_c = ld_u32(bnd, i_c), b_n = ld_u32(bnd, i_n);
+    float b_c = bnd_ld(bnd, i_c), b_n = bnd_ld(bnd, i_n);
     // A step's results are handed to found() (which stores them) at the head of the NEXT step, in front of that step's
     // staging loads: vmcnt counts loads and stores in one in-order queue, so stores issued at the end of a step were what the
     // wait at the head of the next one waited for (20 % of the phase); issued here, the wait that follows them is the one
@@ -1141,7 +1148,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       ST_STAMP(1)
       // the loads of the step after next (the next one's are in flight)
       const F3 q_nn = ld3_u32(mod, i_nn);
-      const float b_nn = ld_u32(bnd, i_nn);
+      const float b_nn = bnd_ld(bnd, i_nn);
       const int i_nnn = ld_u32(perm, min(sb3 + lane, last_s));
       int j = -1;
       float d = NAN;
@@ -1277,7 +1284,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         if (active) {
           nn[i] = j;
           nd[i] = d;
-          if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
+          if (j >= 0) bnd_st(bnd, i, sqrt_upper(d));             // else: the old partner is still within the old bound
         }
       });
   };
@@ -1355,7 +1362,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
             if (active) {
               nn[i] = keep ? j : -1;
-              if (j >= 0) bnd[i] = sqrt_upper(d);             // else: the old partner is still within the old bound
+              if (j >= 0) bnd_st(bnd, i, sqrt_upper(d));             // else: the old partner is still within the old bound
             }
             if (keep) {
               ++kept;
@@ -1366,18 +1373,18 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         const NnGrid G = nn_grid(S);
         int i = threadIdx.x;
         float qx = 0.f, qy = 0.f, qz = 0.f, qb = 0.f;
-        if (i < n_model) { const F3 q3 = ld3_u32(mod, i); qx = q3.x; qy = q3.y; qz = q3.z; qb = ld_u32(bnd, i); }
+        if (i < n_model) { const F3 q3 = ld3_u32(mod, i); qx = q3.x; qy = q3.y; qz = q3.z; qb = bnd_ld(bnd, i); }
         for (; i < n_model; i += BS) {
           const int in = min(i + BS, n_model - 1);           // clamped: unused past the end
           const F3 nq3 = ld3_u32(mod, in);
-          const float nqx = nq3.x, nqy = nq3.y, nqz = nq3.z, nqb = ld_u32(bnd, in);
+          const float nqx = nq3.x, nqy = nq3.y, nqz = nq3.z, nqb = bnd_ld(bnd, in);
           int j = -1;
           float d = NAN;
           if (thr >= 0.f && isfinite(qx) && isfinite(qy) && isfinite(qz))
             nn_search_grid(G, sref, cell_start, qx, qy, qz, nn_radius(qx, qy, qz, fminf(qb, r_thr)), &j, &d);
           const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
           nn[i] = keep ? j : -1;
-          if (j >= 0) bnd[i] = sqrt_upper(d);               // else: the old partner is still within qb
+          if (j >= 0) bnd_st(bnd, i, sqrt_upper(d));               // else: the old partner is still within qb
           if (keep) {
             ++kept;
             if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
