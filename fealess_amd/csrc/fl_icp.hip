@@ -741,8 +741,15 @@ __device__ __forceinline__ void nn_search_grid(const NnGrid &S, const float4 *__
 }
 
 // ---- organised search (recognition / detection: the reference cloud is a back-projected crop) ------------
+// The reference cloud of the organised search is an IMAGE of 12-byte points (crop pixel p -> X, Y, Z; +inf where the paired
+// compaction dropped the pixel) followed by an image of their indices.  The search identifies a reference point by its PIXEL
+// (nn[] holds pixel positions there; ties between equal distances go to the lower pixel, which is the lower index: the
+// compaction is row-major), so the staged records need no index from memory -- 12 instead of 16 bytes per staged point, of a
+// kernel that is bound by the bytes it moves -- and phase A2 gathers the partner from the image instead of from ref[].
+// idximg is read once per frame (tile order) and by the point-to-plane mode (normals are stored by index).
+__host__ __device__ __forceinline__ size_t org_idximg_offset(int pixels) { return (size_t)12 * (size_t)(pixels + 4); }
 struct OrgGeom {
-  int cw, ch;            // crop size: refimg[v * cw + u] holds the point of crop pixel (u, v)
+  int cw, ch;            // crop size: rimg[v * cw + u] holds the point of crop pixel (u, v)
   float offu, offv;      // scene pixel of crop pixel (0, 0) minus the principal point
   float fx, fy;
   float cwm, chm;        // (float)(cw - 1), (float)(ch - 1)
@@ -1007,6 +1014,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   constexpr int BS = SH::BS, NW = SH::NW;
   float *ref = (float *)(wsb + L.ref), *mod = (float *)(wsb + L.mod);
   float4 *sref = (float4 *)(wsb + L.sref);
+  // where the partner of nn[i] = j is read from: the organised search names it by its crop pixel (the image of points),
+  // the grid search by its index (ref[]); idximg maps a pixel to its index (point-to-plane: normals are stored by index)
+  const float *jsrc = ORG ? (const float *)sref : ref;
+  const int *idximg = ORG ? (const int *)((const uint8_t *)sref + org_idximg_offset(og.cw * og.ch)) : nullptr;
   int *nn = (int *)(wsb + L.nn);
   bnd_t *bnd = (bnd_t *)(wsb + L.bnd);
   float *nd = (float *)(wsb + L.nd), *dterm = (float *)(wsb + L.dterm);
@@ -1088,7 +1099,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     static_assert(sizeof(S.prod) + sizeof(S.dtile) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
     static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
     float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
-    const float4 *refimg = sref;
+    const float *rimg = (const float *)sref;
     const int last_s = n_model - 1;
     const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
     constexpr int stride = NW * 64;
@@ -1190,7 +1201,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
               const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
-              R[p] = ld_u32(refimg, min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt));
+              const int pos = min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
+              const F3 pt = ld3_u32(rimg, pos);
+              R[p] = nn_point(pt.x, pt.y, pt.z, pt.x == INFINITY ? NN_IDX_NONE : pos);
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) stage[lane + 64 * p] = R[p];
@@ -1230,7 +1243,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             }
           }
         } else {
-          best = org_scan([&](int idx) { return ld_u32(refimg, idx); }, og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, 4 * nbw, maxh);
+          best = org_scan([&](int idx) { const F3 pt = ld3_u32(rimg, idx); return nn_point(pt.x, pt.y, pt.z, pt.x == INFINITY ? NN_IDX_NONE : idx); },
+                          og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, 4 * nbw, maxh);
         }
         if (queryable) NN_UNPACK(best, &j, &d)
 #ifdef FL_ICP_PHASES
@@ -1330,7 +1344,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       if (plane) {
         // linearised point-to-plane: residual e = n.(m - r), Jacobian row J = [m x n, n] wrt (omega, t);
         // ds = upper triangle of sum J J^T (21) followed by sum J e (6)
-        const F3 nv = ld3_u32(nrm, j);
+        const F3 nv = ld3_u32(nrm, ORG ? ld_u32(idximg, j) : j);
         const float n0 = nv.x, n1 = nv.y, n2 = nv.z;
         const float J[6] = {m1 * n2 - m2 * n1, m2 * n0 - m0 * n2, m0 * n1 - m1 * n0, n0, n1, n2};
         const float e = n0 * (m0 - r0) + n1 * (m1 - r1) + n2 * (m2 - r2);
@@ -1366,7 +1380,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             }
             if (keep) {
               ++kept;
-              if (!parity) { const F3 rv = ld3_u32(ref, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
+              if (!parity) { const F3 rv = ld3_u32(jsrc, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
             }
           });
       } else {
@@ -1429,7 +1443,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       };
       auto row_gather = [&](Row &w) {                      // SPEC: nn[] holds the neighbour whatever its distance; the pair is kept
         if (!(w.in && (!SPEC || w.d <= thr))) w.j = -1;    // if d <= dist_thr (:268; NaN = none found)
-        w.r = ld3_u32(ref, max(w.j, 0));
+        w.r = ld3_u32(jsrc, max(w.j, 0));
       };
       auto row_write = [&](const Row &w, int t) {
         const bool have = w.j >= 0;                        // dropped pairs contribute an exact +0.0f: (+0) * (+0)
@@ -1500,7 +1514,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             if (j >= 0) {
               have_m = have_pair = true;
               m[0] = mod[3 * i]; m[1] = mod[3 * i + 1]; m[2] = mod[3 * i + 2];
-              r[0] = ref[3 * j]; r[1] = ref[3 * j + 1]; r[2] = ref[3 * j + 2];
+              r[0] = jsrc[3 * j]; r[1] = jsrc[3 * j + 1]; r[2] = jsrc[3 * j + 2];
             }
           }
         }
@@ -1696,7 +1710,7 @@ __device__ __forceinline__ void scene_normal(const uint16_t *__restrict__ scene,
 
 template <class SH>
 __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
-                           const int *rm, const int *rr, float *ref, float *mod, float *nrm, float4 *refimg)
+                           const int *rm, const int *rr, float *ref, float *mod, float *nrm, float *rimg, int *idximg)
 {
   constexpr int BS = SH::BS, NW = SH::NW;
   const int cw = rm[2], ch = rm[3], np = cw * ch;
@@ -1740,9 +1754,12 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
     int before = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { const int c = slot[i]; before += i < wv ? c : 0; total += c; }
-    // the reference cloud as an image (organised search): the point and its index, or a point at infinity
-    if (p < np)
-      refimg[p] = keep ? nn_point(A[0], A[1], A[2], kept_before + before + in_wave) : nn_point(INFINITY, INFINITY, INFINITY, NN_IDX_NONE);
+    // the reference cloud as an image (organised search): the point or a point at infinity, and its index
+    if (p < np) {
+      const F3 pt = {keep ? A[0] : INFINITY, keep ? A[1] : INFINITY, keep ? A[2] : INFINITY};
+      __builtin_memcpy(rimg + 3 * p, &pt, 12);
+      idximg[p] = keep ? kept_before + before + in_wave : NN_IDX_NONE;
+    }
     if (keep) {
       const int k = kept_before + before + in_wave;
       ref[3 * k] = A[0]; ref[3 * k + 1] = A[1]; ref[3 * k + 2] = A[2];
@@ -1755,16 +1772,16 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
     }
     kept_before += total;
   }
-  if (threadIdx.x < NN_OVERRUN) refimg[np + threadIdx.x] = nn_point(INFINITY, INFINITY, INFINITY, NN_IDX_NONE);   // overrun guard (org_scan)
+  if (threadIdx.x < 3 * NN_OVERRUN) rimg[3 * np + threadIdx.x] = INFINITY;     // overrun guard: points at infinity behind the image (org_scan)
   __syncthreads();                                         // the clouds are complete for every thread
   return kept_before;
 }
 
 // The model indices in 8x8-pixel tile order (tile rows alternately left-to-right and right-to-left, so consecutive tiles
 // are neighbours): the 64 queries a wave takes per step then project into a compact window of the reference image.
-// Index k of crop pixel p is nn_point_index(refimg[p]) (the paired compaction keeps the same pixels of both clouds).
+// Index k of crop pixel p is idximg[p] (the paired compaction keeps the same pixels of both clouds).
 template <class SH>
-__device__ __forceinline__ void build_tile_order(SH &S, const float4 *refimg, int cw, int ch, int n, int *perm)
+__device__ __forceinline__ void build_tile_order(SH &S, const int *idximg, int cw, int ch, int n, int *perm)
 {
   constexpr int BS = SH::BS, NW = SH::NW;
   int *cnt = (int *)&S.prod[0][0][0];
@@ -1783,7 +1800,7 @@ __device__ __forceinline__ void build_tile_order(SH &S, const float4 *refimg, in
     if (ty & 1) tx = ntx - 1 - tx;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
     int k = NN_IDX_NONE;
-    if (x < cw && y < ch) k = nn_point_index(refimg[y * cw + x]);
+    if (x < cw && y < ch) k = idximg[y * cw + x];
     has = (unsigned)k < (unsigned)NN_IDX_NONE;
     return k;
   };
@@ -1924,14 +1941,15 @@ void k_icp_pipeline(IcpArgs a)
       return;
     }
   }
-  float4 *refimg = (float4 *)(wsb + L.sref);
+  float *rimg = (float *)(wsb + L.sref);                  // image of 12-byte points, then the image of their indices (16 bytes per pixel in all)
   const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod,
-                             MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr, refimg);
+                             MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr, rimg,
+                             (int *)((uint8_t *)rimg + org_idximg_offset(S.rect_m[2] * S.rect_m[3])));
   // wave-uniform values read from LDS are VGPRs unless told otherwise: the search loop keeps them in SGPRs
   const OrgGeom og = {__builtin_amdgcn_readfirstlane(S.rect_r[2]), __builtin_amdgcn_readfirstlane(S.rect_r[3]),
                       uniform_f((float)S.rect_r[0] - a.cx), uniform_f((float)S.rect_r[1] - a.cy), a.fx, a.fy,
                       uniform_f((float)(S.rect_r[2] - 1)), uniform_f((float)(S.rect_r[3] - 1))};
-  build_tile_order(S, refimg, og.cw, og.ch, np, (int *)(wsb + L.perm));
+  build_tile_order(S, (const int *)((const uint8_t *)rimg + org_idximg_offset(og.cw * og.ch)), og.cw, og.ch, np, (int *)(wsb + L.perm));
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
   if (MODE == FL_ICP_PARITY) {
