@@ -30,8 +30,8 @@
 // float expression ((dx*dx + dy*dy) + dz*dz); ties go to the lowest index.
 //
 // Organised search (the recognition / detection() pipeline, where both clouds are back-projected crops).  The grid, its
-// CSR headers and their gathers are not needed there: the reference cloud is kept as an IMAGE (refimg: crop pixel ->
-// point + index, a point at infinity where the pixel was dropped), and the reference points within distance r of a query
+// CSR headers and their gathers are not needed there: the reference cloud is kept as an IMAGE (crop pixel -> 12-byte point,
+// a point at infinity where the pixel was dropped; a point is named by its pixel), and the reference points within distance r of a query
 // q can only come from the pixels its ball projects to -- u in [fx (qx -+ r) / (qz +- r)], likewise v -- a window of a
 // few pixels.  Queries are taken in 8x8-pixel tile order (a permutation built once per frame), so the 64 queries of a
 // wave share a compact union window; the wave stages that window into its share of the (idle) chain tiles in LDS with a
@@ -110,11 +110,13 @@
 // HBM layout of one frame's ICP workspace (n = capacity in points):
 //   ref   n x 3 f32   reference cloud, index order (pairing + iteration 1)
 //   mod   n x 3 f32   model cloud, transformed in place every iteration
-//   sref  (n+4) x float4   (index bits, X, Y, Z).  grid search: reference cloud sorted by grid cell, original index;
-//                     organised search: the reference IMAGE, crop pixel p -> (point, index) or a point at infinity
-//                     with index NN_IDX_NONE where the pixel was dropped by the paired compaction
-//   nn     n x i32    nearest reference index j of model point i (kept pair: j, dropped: -1)
-//   bnd    n x f32    upper bound on the distance from model point i to its nearest reference point
+//   sref  (n+4) x 16 bytes.  grid search: reference cloud sorted by grid cell as float4 (index bits, X, Y, Z);
+//                     organised search: the reference IMAGE, crop pixel p -> X, Y, Z (3 x f32; +inf where the pixel was
+//                     dropped by the paired compaction), then the image of the points' indices (i32, NN_IDX_NONE where dropped)
+//   nn     n x i32    nearest reference point j of model point i (kept pair: j, dropped: -1): its index (grid search) or its
+//                     crop pixel (organised search)
+//   bnd    n x 16 bit upper bound on the distance from model point i to its nearest reference point: the top half of the
+//                     float32 pattern, rounded up (bnd_ld / bnd_st)
 //   nd     n x f32    organised search, parity mode: squared distance to nn[i] (the search runs ahead of the threshold it is
 //                     compared with, see "Search ahead of the distance chain")
 //   dterm  n x f32    parity mode: the terms of getL2distClouds' dist_mean chain, index order (0 for a dropped pair)
@@ -1005,7 +1007,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
 }
 
 // ---- icpCloudToCloud_Ex (ICP.cpp:617-809) --------------------------------------------------------
-// ORG: the reference cloud is also available as the image `og` describes (sref = refimg, perm = tile order), see
+// ORG: the reference cloud is also available as the image `og` describes (sref = image of points + image of indices, perm = tile order), see
 // "Organised search" at the top; otherwise the grid is built here and searched.
 template <int MODE, bool ORG, class SH>
 __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &L, int n_ref, int n_model,
