@@ -269,13 +269,10 @@ class Runner:
         self.w, self.h, self.K, self.bank = w, h, K, bank
         self.det = api.Detector(ctx, 2, t_pyramid(args.levels))
         self.det.add_class(bank)
-        if eager:
-            os.environ["FL_EAGER_FRONTEND"] = "1"      # read by fl_detector_finalize
-        else:
-            os.environ.pop("FL_EAGER_FRONTEND", None)
+        ctx.set_option("eager_frontend", 1 if eager else 0)      # sampled by fl_detector_finalize
         self.B = len(bgrs)
         self.det.finalize(w, h, max_batch=self.B, max_candidates=max_candidates)
-        os.environ.pop("FL_EAGER_FRONTEND", None)
+        ctx.set_option("eager_frontend", 0)
         self.d_bgr = torch.from_numpy(bgrs).cuda()
         self.d_depth = torch.from_numpy(depths.view(np.int16)).cuda()
         torch.cuda.synchronize()
@@ -519,15 +516,14 @@ def pmc_traffic(args, bank, kernel):
 
 
 def unpruned_scan_ms(run, n=None, steps=3):
-    """k_scan's duration with the exact pruning between modalities switched off (FL_SCAN_PRUNE=0 is read at every launch): the
-    kernel then performs every addition SURVEY 8(d)'s N * B_tmpl counts, which is what a bytes-per-second figure must be
-    computed on."""
-    os.environ["FL_SCAN_PRUNE"] = "0"
+    """k_scan's duration with the exact pruning switched off (option scan_prune = 0): the kernel then performs every
+    addition SURVEY 8(d)'s N * B_tmpl counts, which is what a bytes-per-second figure must be computed on."""
+    run.ctx.set_option("scan_prune", 0)
     try:
         run.timed(steps, 1, n=n)
         _, t = run.collect(n)
     finally:
-        os.environ.pop("FL_SCAN_PRUNE", None)
+        run.ctx.set_option("scan_prune", 1)
     return t["scan_ms"]
 
 
@@ -550,14 +546,19 @@ def line_c2(args, run, res, times, value, el, world, bank, T, bgrs, depths, sync
     # what the fused kernel needs: the same iterations, but only the two template-sized crops are back-projected
     crop_px = sum(int(tpl[int(r.best.template_id) * LM]["width"]) * int(tpl[int(r.best.template_id) * LM]["height"]) for r in res if r.found)
     icp_bytes_need = iter_bytes + 2 * 14 * crop_px
-    kern = {"k_scan": dict(ms=times["scan_ms"], bytes=scan_bytes), "k_icp_pipeline": dict(ms=times["icp_ms"], bytes=float(icp_bytes_8d))}
+    # `frac` is quoted on the bytes the fused kernel NEEDS (SURVEY 8(d)'s per-iteration figure and the back-projection of the two
+    # template-sized crops it performs); 8(d)'s own B_icp also counts the reference's two full-frame back-projections, which the
+    # kernel never does -- that larger numerator is carried as `survey_8d`, never as `frac`
+    kern = {"k_scan": dict(ms=times["scan_ms"], bytes=scan_bytes), "k_icp_pipeline": dict(ms=times["icp_ms"], bytes=float(icp_bytes_need))}
     dom = max(kern, key=lambda k: kern[k]["ms"])
     ach = gbs(kern[dom]["bytes"], kern[dom]["ms"])
     traffic, traffic_detail = pmc_traffic(args, bank, dom)
     roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 5), traffic=traffic, launch_ms=round(kern[dom]["ms"], 4),
                     algorithmic_bytes_per_launch=kern[dom]["bytes"],
-                    numerator="SURVEY 8(d): B_icp = iters*n*72 + 2*14*W*H per frame" if dom == "k_icp_pipeline" else "SURVEY 8(d): N*B_tmpl per frame",
+                    numerator=("iters*n*72 per frame (SURVEY 8(d): 24 correspondences + 24 transform + 24 distances per point and iteration) + "
+                               "2*14*w*h of the two template-sized crops the fused kernel back-projects") if dom == "k_icp_pipeline"
+                    else "SURVEY 8(d): N*B_tmpl per frame",
                     traffic_detail=traffic_detail)
     if traffic:
         moved = gbs(traffic, kern[dom]["ms"])
@@ -566,10 +567,11 @@ def line_c2(args, run, res, times, value, el, world, bank, T, bgrs, depths, sync
                                         note="the counter traffic over this launch's duration: what the memory side actually moves "
                                              "(Infinity-Cache hits are counted too); achievable HBM is about 6.3 TB/s")
     if dom == "k_icp_pipeline":
-        a2 = gbs(icp_bytes_need, times["icp_ms"])
-        roofline["kernel_needs"] = dict(achieved=round(a2, 2), frac=round(a2 / HBM_PEAK_GBS, 5), bytes_per_launch=float(icp_bytes_need),
-                                        note="iterations' bytes + back-projection of the two template-sized crops the fused kernel actually "
-                                             "performs (the reference back-projects both full frames: that term is 2*14*W*H in `frac`)")
+        a2 = gbs(icp_bytes_8d, times["icp_ms"])
+        roofline["survey_8d"] = dict(achieved=round(a2, 2), frac=round(a2 / HBM_PEAK_GBS, 5), bytes_per_launch=float(icp_bytes_8d),
+                                     note="SURVEY 8(d)'s B_icp as written: iters*n*72 + 2*14*W*H per frame, i.e. with the reference's two "
+                                          "FULL-FRAME back-projections, which the fused kernel does not perform -- a flattering numerator, "
+                                          "kept for comparison with earlier rounds only")
     scan_full_ms = unpruned_scan_ms(run)
     scan_ach = gbs(scan_bytes, scan_full_ms)
     pcie = None
@@ -617,7 +619,7 @@ def line_c2(args, run, res, times, value, el, world, bank, T, bgrs, depths, sync
                         "achieved_GBs": round(scan_ach, 1), "frac": round(scan_ach / HBM_PEAK_GBS, 4),
                         "l2_frac": round(scan_ach / L2_PEAK_GBS, 4), "l2_peak_GBs": L2_PEAK_GBS,
                         "note": "achieved_GBs / l2_frac: algorithmic bytes (SURVEY 8d N*B_tmpl) over the duration of the UNPRUNED kernel "
-                                "(FL_SCAN_PRUNE=0: every addition performed); the linear memories are L2-resident, so the meaningful roof is "
+                                "(option scan_prune = 0: every addition performed); the linear memories are L2-resident, so the meaningful roof is "
                                 "the aggregate L2 bandwidth (l2_frac), not HBM (frac may exceed 1).  scan_ms is the kernel the headline runs: "
                                 "it stops a (template, chunk) between the modalities once no position can reach the coarse threshold "
                                 "(exact, data-dependent: same match lists)"},
@@ -637,7 +639,7 @@ def line_c3(args, run, res, times, value, el, world, bank, T):
                     pruned_launch_ms=round(times["scan_ms"], 4),
                     algorithmic_bytes_per_launch=scan_bytes, numerator="SURVEY 8(d): N*B_tmpl per frame",
                     l2_frac=round(scan_ach / L2_PEAK_GBS, 5), l2_peak=L2_PEAK_GBS, traffic_detail=traffic_detail,
-                    note="launch_ms / achieved / frac: the UNPRUNED kernel (FL_SCAN_PRUNE=0: every addition of N*B_tmpl performed); `value` runs "
+                    note="launch_ms / achieved / frac: the UNPRUNED kernel (option scan_prune = 0: every addition of N*B_tmpl performed); `value` runs "
                          "the pruning kernel (pruned_launch_ms: a (template, chunk) stops between the modalities once no position can reach "
                          "the threshold -- exact, data-dependent).  The scan's linear memories are L2-resident: judge it against the L2 roof "
                          "(l2_frac); longest stage of the step: " + dom)
@@ -692,19 +694,19 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
                                           "data-independent figure; same results")
         r3.close()
     # the whole step with the scan's exact pruning off: with eager_frontend the data-independent figures
-    os.environ["FL_SCAN_PRUNE"] = "0"
+    ctx.set_option("scan_prune", 0)
     try:
         el = run.timed(4, 1)
         _, t = run.collect()
     finally:
-        os.environ.pop("FL_SCAN_PRUNE", None)
+        ctx.set_option("scan_prune", 1)
     out["scan_unpruned"] = dict(value=round(args.batch * 4 / el, 1), unit="frames/s", ms_per_step=round(el / 4 * 1e3, 4),
                                 scan_ms=round(t["scan_ms"], 4),
-                                note="FL_SCAN_PRUNE=0: every template's every feature added at every position (the reference's work); "
+                                note="option scan_prune = 0: every template's every feature added at every position (the reference's work); "
                                      "same results")
     if args.icp_mode == "parity":
-        # FL_ICP_FAST (parallel sums instead of the reference's float32 chains): not bit-identical to the reference's arithmetic,
-        # within the north_star's 1e-4 of it (tests/test_gpu_icp.py::test_icp_fast_mode_vs_the_f32_oracle_and_fp64)
+        # FL_ICP_FAST (parallel sums instead of the reference's float32 chains): within 1e-4 of the EXACT sums, not of the reference's
+        # float32 result (tests/test_gpu_icp.py::test_icp_fast_mode_close_to_fp64_yardstick, ::test_icp_fast_mode_recognition_vs_the_f32_oracle)
         af = argparse.Namespace(**vars(args))
         af.icp_mode = "fast"
         r4 = Runner(ctx, af, bank, bgrs, depths, w, h, K)
@@ -715,7 +717,11 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
         out["icp_fast"] = dict(value=round(args.batch * 4 / el, 1), unit="frames/s", ms_per_step=round(el / 4 * 1e3, 4),
                                icp_ms=round(t["icp_ms"], 4), batch1_latency_ms=round(el1 / 20 * 1e3, 4), batch1_icp_ms=round(t1["icp_ms"], 4),
                                note="--icp-mode fast: float32 per-thread partial sums + fp64 tree instead of the reference-order float32 chains; "
-                                    "pose within 1e-4 (R) of the float32 oracle, not bit-identical; never the headline value")
+                                    "final pose within 1e-4 of the exact (fp64) sums; up to 1.1e-4 (R) / 1.1e-4 (T relative to the object's "
+                                    "distance) from the reference's float32 result on 15 k-point clouds, which is that result's own "
+                                    "summation noise (the tests assert <= 2.5e-4 and no farther than the float32 result is from the exact "
+                                    "sums); NOT the mode that meets the 1e-4 bar against the reference -- FL_ICP_PARITY does, with 0; never "
+                                    "the headline value")
         r4.close()
     run.close()                                           # the default workload's 16 GB of workspaces make room for the other configs
     out.update(other_configs(args, ctx))

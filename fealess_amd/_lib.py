@@ -78,6 +78,8 @@ SIGNATURES = {
     "fl_last_error": (C.c_char_p, [_P]),
     "fl_context_set_stream": (_I, [_P, _P]),
     "fl_context_synchronize": (_I, [_P]),
+    "fl_context_set_option": (_I, [_P, C.c_char_p, C.c_long]),
+    "fl_context_get_option": (_I, [_P, C.c_char_p, C.POINTER(C.c_long)]),
     "fl_detector_create": (_I, [_P, _I, _I, C.POINTER(_I), C.POINTER(_P)]),
     "fl_detector_destroy": (None, [_P]),
     "fl_detector_add_class": (_I, [_P, C.c_char_p, _I, _P, _P, _I, _P]),

@@ -50,6 +50,15 @@ class Context:
     def synchronize(self):
         self.check(self.lib.fl_context_synchronize(self.h))
 
+    def set_option(self, name, value):
+        """Development / comparison switch (fl_context_set_option): speed only, results identical."""
+        self.check(self.lib.fl_context_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_long()
+        self.check(self.lib.fl_context_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def close(self):
         if self.h:
             self.lib.fl_context_destroy(self.h)

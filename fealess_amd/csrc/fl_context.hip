@@ -56,6 +56,18 @@ int fl_pinned(fl_context *ctx, size_t bytes, void **out)
 
 extern "C" int fl_abi_version(void) { return FL_ABI_VERSION; }
 
+struct FlOptionName { const char *name, *env; long fl_context::Options::*field; bool hex; };
+static const FlOptionName fl_option_names[] = {
+  {"scan_prune", "FL_SCAN_PRUNE", &fl_context::Options::scan_prune, false},
+  {"scan_prune_mid", "FL_SCAN_PRUNE_MID", &fl_context::Options::scan_prune_mid, true},
+  {"icp_wide", "FL_ICP_WIDE", &fl_context::Options::icp_wide, false},
+  {"icp_occ", "FL_ICP_OCC", &fl_context::Options::icp_occ, false},
+  {"icp_order", "FL_ICP_ORDER", &fl_context::Options::icp_order, false},
+  {"eager_frontend", "FL_EAGER_FRONTEND", &fl_context::Options::eager_frontend, false},
+  {"dev_poison", "FL_DEV_POISON", &fl_context::Options::dev_poison, false},
+  {"ws_pad", "FL_DEV_WS_PAD", &fl_context::Options::ws_pad, false},
+};
+
 extern "C" int fl_context_create(int device, fl_context **out)
 {
   if (!out) return FL_ERR_INVALID;
@@ -71,8 +83,39 @@ extern "C" int fl_context_create(int device, fl_context **out)
     return FL_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cus = prop.multiProcessorCount;
+  }
+  if (hipMalloc((void **)&ctx->d_cu_chain, sizeof(unsigned) * FL_CU_TABLE) != hipSuccess ||
+      hipMemset(ctx->d_cu_chain, 0, sizeof(unsigned) * FL_CU_TABLE) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ctx->d_cu_chain) (void)hipFree(ctx->d_cu_chain);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return FL_ERR_HIP;
+  }
+  // the development switches' initial values: the environment is read here and nowhere else
+  for (const FlOptionName &o : fl_option_names)
+    if (const char *e = getenv(o.env)) ctx->opt.*(o.field) = o.hex ? (long)strtoul(e, nullptr, 16) : atol(e);
   *out = ctx;
   return FL_OK;
+}
+
+extern "C" int fl_context_set_option(fl_context *ctx, const char *name, long value)
+{
+  if (!ctx || !name) return FL_ERR_INVALID;
+  for (const FlOptionName &o : fl_option_names)
+    if (!strcmp(name, o.name)) { ctx->opt.*(o.field) = value; return FL_OK; }
+  return fl_set_error(ctx, FL_ERR_INVALID, "unknown option '%s'", name);
+}
+
+extern "C" int fl_context_get_option(const fl_context *ctx, const char *name, long *value)
+{
+  if (!ctx || !name || !value) return FL_ERR_INVALID;
+  for (const FlOptionName &o : fl_option_names)
+    if (!strcmp(name, o.name)) { *value = ctx->opt.*(o.field); return FL_OK; }
+  return FL_ERR_INVALID;
 }
 
 // A context outlives the detectors created on it whatever order the caller destroys them in: fl_context_destroy on a
@@ -82,6 +125,7 @@ static void context_release(fl_context *ctx)
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->d_cu_chain) (void)hipFree(ctx->d_cu_chain);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -343,7 +387,7 @@ static int layout_workspace(fl_detector *det, int cap)
   det->off_icp = take(fl_icp_ws_bytes(det->n_pts_max));
   det->ws_stride = fl_align(off, 4096);
   det->cap = cap;
-  if (const char *pad = getenv("FL_DEV_WS_PAD")) det->ws_stride += fl_align((size_t)atol(pad), 4096);   // dev aid: stride sensitivity
+  if (ctx->opt.ws_pad > 0) det->ws_stride += fl_align((size_t)ctx->opt.ws_pad, 4096);   // dev aid: stride sensitivity
   if (hipMalloc((void **)&det->d_ws, det->ws_stride * (size_t)det->max_batch) != hipSuccess) {
     det->d_ws = nullptr;
     (void)hipGetLastError();
@@ -557,9 +601,10 @@ extern "C" int fl_detector_finalize(fl_detector *det, int w0, int h0, int max_ba
   det->w0 = w0;
   det->h0 = h0;
   det->max_batch = max_batch;
-  { const char *e = getenv("FL_EAGER_FRONTEND"); det->eager_env = e && *e && *e != '0'; }
-  { const char *e = getenv("FL_DEV_POISON"); det->poison_env = e && *e && *e != '0'; }
+  det->eager_env = ctx->opt.eager_frontend != 0;          // development switches (fl_context_set_option), sampled here
+  det->poison_env = ctx->opt.dev_poison != 0;
   if ((rc = layout_workspace(det, cap))) return rc;
+  if ((rc = fl_icp_prepare(det))) return rc;
   FL_HIP(ctx, hipMalloc((void **)&det->d_results, sizeof(fl_recognition_result) * (size_t)max_batch));
   FL_HIP(ctx, hipHostMalloc((void **)&det->h_results, sizeof(fl_recognition_result) * (size_t)max_batch,
                             hipHostMallocDefault));

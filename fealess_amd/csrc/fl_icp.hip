@@ -44,6 +44,9 @@
 #include <math.h>
 #include <string.h>
 #include <type_traits>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #define ICP_BS_SMALL 256
 #define ICP_BS_WIDE 1024
@@ -84,19 +87,23 @@
 #ifndef FL_ICP_NBQ
 #define FL_ICP_NBQ 4              // organised search: candidate positions fetched per batch (4 VGPRs each)
 #endif
-#ifndef FL_ICP_PD
-#define FL_ICP_PD 1               // chain phases, parity mode: tiles whose loads a producer thread keeps in flight (phase A2: the
-                                  // dependent gather ref[nn[i]] runs FL_ICP_PD tiles ahead, nn / mod one more; phase B: mod / ref / bnd).
-                                  // Measured at 2048 frames: 1 / 2 / 3 / 4 -> 20.93 / 20.86 / 21.04 / 20.92 ms: the chain phases do not
-                                  // wait for the producers' loads
-#endif
-#ifndef FL_ICP_SPLIT
-#define FL_ICP_SPLIT 1            // chain phases: the chain wave and the producer waves run separate loops (same barrier count), so
-                                  // the chain's register batches do not share a live range with the producers' pipeline state
-#endif
 #ifndef FL_ICP_NBUF_SMALL
 #define FL_ICP_NBUF_SMALL 2       // 16-row register batches of a chain in the 256-thread kernel (with the split loops 2 / 3 / 4 measure
                                   // the same 20.8-20.9 ms per 2048 frames: the chains do not wait for their LDS reads either)
+#endif
+#ifndef FL_ICP_BSUM
+#define FL_ICP_BSUM 1             // parity mode: the dist_mean chain (non-negative terms) adds whole blocks exactly (chain_block_nonneg) and falls
+                                  // back to the term-by-term chain only where a block holds a rounding tie or crosses a binade.  1: in the
+                                  // 1024-thread kernel (a frame alone on its CU waits for that chain: ICP 3.07 -> 2.71 ms per 8 frames);
+                                  // 2: in the 256-thread kernel too (measured at 4096 frames: 34.1 against 33.5 ms -- with four workgroups
+                                  // per CU nobody waits for the chain, and a phase B that runs as fast as memory lets it only takes the
+                                  // memory side from the co-resident workgroups' phases); 0: always term by term
+#endif
+#ifndef FL_ICP_ALLPROD
+#define FL_ICP_ALLPROD 1          // with the block sums in the 256-thread kernel: the chain wave produces rows too (tiles of 256 rows)
+#endif
+#ifndef FL_ICP_CHAIN_SIMD
+#define FL_ICP_CHAIN_SIMD 1       // 256-thread kernel: elect the chain wave so that the chain waves of a CU's workgroups sit on different SIMDs
 #endif
 #ifndef FL_ICP_SPEC
 #define FL_ICP_SPEC 1             // parity mode, organised search: the next iteration's search runs while the chain wave adds dist_mean
@@ -183,6 +190,7 @@ struct IcpArgs {
   fl_recognition_result *results;
   const FlRefineJob *jobs;     // kind 0 with caller-chosen matches (fl_refine_matches): job b refines jobs[b].match on frame jobs[b].frame
   const int *order;            // kind 0 batches: workgroup b runs job order[b] (longest first, see k_icp_order); null: job b
+  unsigned *cu_chain;          // per-CU bookings of the chain waves' SIMDs (chain_elect); null: wave 0 chains
 };
 
 // LDS state of one frame workgroup of BS_ threads.  Parity mode: virtual wave 0 chains, the other BS/64 - 1 waves
@@ -197,12 +205,27 @@ struct IcpSharedT {
   static constexpr int NPROD = NW >= 8 ? NW - NW / 4 : NW - 1;
   static constexpr int CHAIN_NBUF = BS_ >= 1024 ? 4 : FL_ICP_NBUF_SMALL;
   static constexpr int TQ = NPROD * 64;   // rows per LDS tile
+  // Which wave chains.  The 1024-thread workgroup: wave 0.  The 256-thread one: wave `cw`, elected per workgroup so that the
+  // chain waves of the workgroups that share a CU sit on DIFFERENT SIMDs (chain_elect): a chain wave issues one dependent
+  // add per 8 cycles -- half of its SIMD's issue slots for one to fifteen useful lanes -- and two of them on one SIMD leave
+  // the other two waves of that SIMD the scraps while the neighbouring SIMDs idle.
+  int cw;
+  int wsimd[NW];                         // chain_elect: the SIMD each wave runs on
+  int cu_slot, cu_simd;                  // chain_elect: what this workgroup booked in the per-CU table (cu_slot < 0: nothing)
   // tile row of this thread, or -1 (chain wave / idle wave)
-  static __device__ __forceinline__ int producer_slot()
+  __device__ __forceinline__ int producer_slot() const
   {
     const int t = (int)threadIdx.x, w = t >> 6;
     if (NW >= 8) return (w & 3) == 0 ? -1 : t - 64 * (1 + (w >> 2));
-    return t - 64;
+    const int v = (w - __builtin_amdgcn_readfirstlane(cw) - 1) & (NW - 1);     // producers are virtual waves 0 .. NW - 2
+    return v == NW - 1 ? -1 : v * 64 + (t & 63);
+  }
+  // lane of this thread in the chain wave, or -1
+  __device__ __forceinline__ int chain_lane() const
+  {
+    const int t = (int)threadIdx.x;
+    if (NW >= 8) return t < 64 ? t : -1;
+    return (t >> 6) == __builtin_amdgcn_readfirstlane(cw) ? (t & 63) : -1;
   }
   static constexpr int TS = TQ + 4;       // tile column stride (floats): 16-byte aligned columns for ds_read_b128; the +4
                                           // keeps the 16 chain lanes of a b128 read on distinct bank groups
@@ -223,7 +246,11 @@ struct IcpSharedT {
   // double-buffered LDS tiles feeding the sequential float32 chains (FL_ICP_PARITY):
   // prod[b][k][r] = scalar k (9 products, 3 model coords, 3 reference coords) of row r of tile b
   alignas(16) float prod[2][15][TS];
-  alignas(16) float dtile[2][TQ];
+  // rows per tile of the dist_mean phase: with the exact block sums the chain wave of a 4-wave workgroup has time to produce too
+  static constexpr bool BSUM = FL_ICP_BSUM == 2 || (FL_ICP_BSUM == 1 && NW >= 8);   // exact block sums of the dist_mean chain in this kernel
+  static constexpr bool ALLPROD = BSUM && FL_ICP_ALLPROD && NW < 8;
+  static constexpr int DTQ = ALLPROD ? BS_ : TQ;
+  alignas(16) float dtile[2][DTQ];
   alignas(16) float dchain[2][ICP_DT];   // the deferred dist_mean chain's staging (chain wave only)
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
@@ -234,6 +261,14 @@ struct IcpSharedT {
 };
 
 __device__ __forceinline__ bool vvalid(float z) { return z <= 900.0f; }      // common.cpp:261-266
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+// float -> int as the hardware converts: saturating, NaN -> 0 (a C cast of an out-of-range value is undefined)
+__device__ __forceinline__ int cvt_i32_sat(float f)
+{
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
 
 // ---- block-level helpers (every thread of the workgroup must call) ---------------------------
 template <class SH>
@@ -443,6 +478,63 @@ __device__ __forceinline__ float chain_tile(const float *col, int rows, float ac
   return acc;
 }
 
+// ---- exact block sums of a float32 chain with non-negative terms (getL2distClouds' dist_mean, ICP.cpp:68-111) ----------
+// acc <- fl(fl(fl(acc + x0) + x1) + ...) is a chain of dependent adds (8.25 cycles each, one useful lane).  But while the
+// running sum stays inside ONE binade [2^e, 2^(e+1)), every float it can take is a multiple of u = 2^(e-23), and
+// fl(s + x) = s + rne(x / u) u for a multiple s of u -- unless x / u lies exactly half way between two integers (then the
+// parity of s decides).  So for a block of terms x_k >= 0 (the sum only grows): if no x_k / u is a tie and
+// acc / u + sum_k rne(x_k / u) < 2^24, the chain's result after the block is exactly that integer times u, whatever the
+// order -- a wave-wide integer reduction instead of 64 x N dependent adds.  Ties (about 1 term in 2^(e - e_x)) and binade
+// crossings (log2 of the sum over a whole cloud) make the block fall back to the term-by-term chain.  Bit-identical by
+// construction; x * 2^(23-e) is exact (a power of two; an underflow rounds to a value below 1/2, which still rounds to 0).
+struct BlkScale {
+  float scale, ulp;      // 2^(23-e), 2^(e-23)
+  int ai;                // acc / ulp, in [2^23, 2^24)
+  bool ok;               // acc is a positive normal float whose scale and ulp are normal too
+};
+__device__ __forceinline__ BlkScale blk_scale(float acc)
+{
+  BlkScale b;
+  const unsigned eb = __float_as_uint(acc) >> 23;          // sign + exponent: a negative, zero, denormal, inf or NaN acc fails the test
+  b.ok = eb >= 24u && eb <= 254u;
+  const unsigned e2 = b.ok ? eb : 127u;
+  b.scale = __uint_as_float((277u - e2) << 23);
+  b.ulp = __uint_as_float((e2 - 23u) << 23);
+  b.ai = cvt_i32_sat(acc * b.scale);
+  return b;
+}
+#define BLK_LANE_MAX 2097152.0f                             // 2^21: 768 terms below it sum to less than 2^31
+__device__ __forceinline__ void blk_term(const BlkScale &b, float x, int &isum, bool &bad)
+{
+  const float y = x * b.scale, q = __builtin_rintf(y), f = y - q;
+  bad = bad || !(x >= 0.0f) || !(y < BLK_LANE_MAX) || __builtin_fabsf(f) == 0.5f;
+  isum += cvt_i32_sat(q);
+}
+// wave-wide: true and the new sum in acc if the block could be added exactly
+__device__ __forceinline__ bool blk_finish(const BlkScale &b, int isum, bool bad, float &acc)
+{
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) isum += __shfl_xor(isum, s, 64);
+  const int ni = b.ai + isum;
+  if (!b.ok || __ballot(bad) != 0ull || ni >= (1 << 24) || isum < 0) return false;
+  acc = (float)ni * b.ulp;
+  return true;
+}
+// all 64 lanes of the chain wave: acc + col[0 .. rows), as the term-by-term chain would leave it; every lane returns the sum
+template <int NBUF>
+__device__ __forceinline__ float chain_block_nonneg(const float *col, int rows, float acc)
+{
+  const int lane = threadIdx.x & 63;
+  const BlkScale b = blk_scale(acc);
+  int isum = 0;
+  bool bad = false;
+  for (int r = lane; r < rows; r += 64) blk_term(b, col[r], isum, bad);
+  if (blk_finish(b, isum, bad, acc)) return acc;
+  float r = acc;
+  if (lane == 0) r = chain_tile<NBUF>(col, rows, acc);
+  return uniform_f(r);
+}
+
 // The deferred dist_mean chain (executed by ONE wave, all 64 lanes enter): dterm[0 .. n) added strictly in order by lane 0.
 // The wave streams the terms from HBM ICP_DT at a time (two coalesced float4 per lane, the next block in flight while
 // this one is added) through its own LDS buffer `buf` (2 x ICP_DT floats); the array is padded to whole blocks.
@@ -458,19 +550,35 @@ __device__ __forceinline__ float chain_deferred(const float *__restrict__ dterm,
     r1 = *(const float4 *)(dterm + 256 + 4 * lane);
   }
   for (int b = 0; b < nblk; ++b) {
-    float *dst = buf[b & 1];
-    *(float4 *)(dst + 4 * lane) = r0;
-    *(float4 *)(dst + 256 + 4 * lane) = r1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int cnt = min(ICP_DT, n - b * ICP_DT);
+    const float4 c0 = r0, c1 = r1;
     if (b + 1 < nblk) {
       r0 = *(const float4 *)(dterm + (size_t)(b + 1) * ICP_DT + 4 * lane);
       r1 = *(const float4 *)(dterm + (size_t)(b + 1) * ICP_DT + 256 + 4 * lane);
     }
-    if (lane == 0) acc = chain_tile<NBUF>(dst, min(ICP_DT, n - b * ICP_DT), acc);
+#if FL_ICP_BSUM
+    {
+      // the block straight from the registers it arrived in, as one exact integer sum (chain_block_nonneg); the words behind
+      // term n - 1 of the last block are padding
+      const BlkScale bs = blk_scale(acc);
+      int isum = 0;
+      bool bad = false;
+      const float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) blk_term(bs, (k < 4 ? 4 * lane + k : 256 + 4 * lane + k - 4) < cnt ? v[k] : 0.0f, isum, bad);
+      if (blk_finish(bs, isum, bad, acc)) continue;
+    }
+#endif
+    float *dst = buf[b & 1];
+    *(float4 *)(dst + 4 * lane) = c0;
+    *(float4 *)(dst + 256 + 4 * lane) = c1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) acc = chain_tile<NBUF>(dst, cnt, acc);
+    acc = uniform_f(acc);
   }
-  return acc;                                            // lane 0's value is the sum
+  return acc;                                            // every lane holds the sum
 }
 
 // uniform base + 32-bit unsigned byte offset: one VGPR per address (global_load ... v_off, s[base]) instead of a
@@ -493,10 +601,19 @@ __device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
 
 // bnd[] is only ever an UPPER bound (a wider search radius visits more pixels, the neighbour found is the same), so it is kept
 // as the top 16 bits of its float32 pattern, rounded UP: 8 of the ~155 bytes the kernel moves per point and iteration.
-// (+inf and NaN stay what they are: both mean "no bound".)
+// Saturating: a finite value rounds up to at most +inf (0x7F80), and ANY NaN payload is stored as the canonical 0x7FC0 -- "no
+// bound" -- instead of carrying into the exponent or the sign (0x7FFFxxxx + 0xFFFF would wrap to 0x8000 = a bound of -0).
+// bnd values are non-negative by construction (distances and sums of distances).
 typedef uint16_t bnd_t;
+// (three instructions: every pattern at or above the canonical NaN -- the negative ones included -- is clamped to it first;
+// the NaNs below it round up to a NaN no larger than it; FLT_MAX rounds up to +inf)
+__host__ __device__ __forceinline__ uint16_t bnd_pack(unsigned bits)
+{
+  return (uint16_t)(((bits < 0x7FC00000u ? bits : 0x7FC00000u) + 0xFFFFu) >> 16);
+}
+extern "C" unsigned fl_dev_bnd_pack(unsigned bits) { return bnd_pack(bits); }      // for tests/test_abi_cpu.py (host arithmetic, no GPU)
 __device__ __forceinline__ float bnd_ld(const bnd_t *__restrict__ b, int i) { return __uint_as_float((unsigned)ld_u32(b, i) << 16); }
-__device__ __forceinline__ void bnd_st(bnd_t *b, int i, float v) { b[i] = (bnd_t)((__float_as_uint(v) + 0xFFFFu) >> 16); }
+__device__ __forceinline__ void bnd_st(bnd_t *b, int i, float v) { b[i] = bnd_pack(__float_as_uint(v)); }
 
 // An UPPER bound of sqrt(x) for the search-radius bookkeeping (bnd[]): the hardware's 1-ulp v_sqrt_f32 inflated past
 // its error (and past a flushed denormal) instead of the ~15-instruction correctly rounded sqrtf.  Any over-estimate
@@ -644,7 +761,6 @@ struct NnGrid {
   float xmin, ymin, inv_c;
   int GX, GY, nsorted;
 };
-__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 template <class SH>
 __device__ __forceinline__ NnGrid nn_grid(const SH &S)
 {
@@ -788,13 +904,6 @@ __device__ __forceinline__ void wave_max_multi(int (&v)[N])
   for (int k = 0; k < N; ++k) v[k] = __builtin_amdgcn_readlane(v[k], 63);
 }
 
-// float -> int as the hardware converts: saturating, NaN -> 0 (a C cast of an out-of-range value is undefined)
-__device__ __forceinline__ int cvt_i32_sat(float f)
-{
-  int r;
-  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
-  return r;
-}
 
 // The crop pixels whose points can lie within distance r of q: a point (X, Y, Z) of pixel (su, sv) satisfies
 // su - cx = X fx / Z up to float rounding (it was generated as X = ((su - cx) / fx) Z), and |X - qx|, |Z - qz| <= r.
@@ -875,8 +984,12 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
                                              const float *Ropt, const float *Topt)
 {
   constexpr bool parity = MODE == FL_ICP_PARITY && !DEFER;   // chains in this phase
-  constexpr int TQ = parity ? SH::TQ : SH::BS;           // rows per tile: wave 0 only chains in parity mode
-  const int slot = parity ? SH::producer_slot() : (int)threadIdx.x;
+  // With the exact block sums (FL_ICP_BSUM) the chain costs its wave a few dozen instructions per tile, so in the 4-wave
+  // workgroup the chain wave produces as well: tiles of BS rows, four producer waves instead of three.
+  constexpr bool allprod = parity && SH::ALLPROD;
+  constexpr int TQ = parity && !allprod ? SH::TQ : SH::BS;   // rows per tile
+  const int slot = parity && !allprod ? S.producer_slot() : (int)threadIdx.x;
+  const int clane = parity ? S.chain_lane() : -1;        // lane of this thread in the chain wave, or -1
   int counter = 0, inl = 0;
   double dsum[1] = {0.0};
   float acc = 0.0f;
@@ -940,12 +1053,35 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
       __builtin_amdgcn_s_barrier();
     }
   };
-  const bool chain_wave = parity && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
-  if (chain_wave) {
+  // tile t is complete in LDS: the chain wave adds it (every lane of the wave enters)
+  auto chain_step = [&](int t) {
+    const float *col = S.dtile[t & 1];
+    const int rows = min(TQ, n - t * TQ);
+    if (SH::BSUM) acc = chain_block_nonneg<SH::CHAIN_NBUF>(col, rows, acc);
+    else if (clane == 0) acc = chain_tile<SH::CHAIN_NBUF>(col, rows, acc);
+  };
+  const bool chain_wave = __builtin_amdgcn_readfirstlane(clane) >= 0;
+  if (allprod) {
+    // every wave produces; the chain wave adds tile t - 1 (complete since the last barrier, the other buffer) behind its own rows of tile t
+    Row A, B;
+    if (ntiles > 0) row_load(A, 0);
+    for (int t = 0; t < ntiles; t += 2) {
+      row_load(B, t + 1);
+      row_process(A, t);
+      if (chain_wave && t > 0) chain_step(t - 1);
+      PR_STAMP_BARRIER(28, 2);
+      if (t + 1 < ntiles) {
+        row_load(A, t + 2);
+        row_process(B, t + 1);
+        if (chain_wave) chain_step(t);
+        tile_barrier();
+      }
+    }
+  } else if (chain_wave) {
     // the chain wave's own loop (see the A2 phase): one barrier per tile like the producers' below
     CH_STAMP_BEGIN;
     for (int t = 0; t < ntiles; ++t) {
-      if (t > 0 && threadIdx.x == 0) acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(t - 1) & 1], min(TQ, n - (t - 1) * TQ), acc);
+      if (t > 0) chain_step(t - 1);
       CH_STAMP(c_add);
       tile_barrier();
       CH_STAMP(c_bar);
@@ -968,8 +1104,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
     for (int t = 0; t < ntiles; ++t) tile_barrier();       // a wave that neither chains nor produces (1024-thread workgroup)
   }
   __syncthreads();                                         // the phase's stores (mod, bnd, dterm) are visible to the workgroup
-  if (parity && ntiles > 0 && threadIdx.x == 0)
-    acc = chain_tile<SH::CHAIN_NBUF>(S.dtile[(ntiles - 1) & 1], min(TQ, n - (ntiles - 1) * TQ), acc);
+  if (parity && ntiles > 0 && chain_wave) chain_step(ntiles - 1);
   counter = block_sum_int(S, counter);
   inl = block_sum_int(S, inl);
   if (DEFER) {
@@ -985,7 +1120,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   }
   float dm;
   if (parity) {
-    if (threadIdx.x == 0) S.sums[0] = acc;
+    if (clane == 0) S.sums[0] = acc;
     __syncthreads();
     dm = S.sums[0];
     if (counter > 0) dm /= (float)inl;                   // 0/0 -> NaN ends the loop (Q9)
@@ -1220,6 +1355,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
           ST_STAMP(2)
           // scan: maxh rows (a lane with fewer re-reads its last one) of nbw batches of 4 consecutive points (a window narrower
           // than 4 reads on into the next points of its row, of the next row, or of the slots behind the rectangle)
+          static_assert(FL_ICP_NBQ == 4 && NN_OVERRUN == 3, "the staged scan is written for 4-wide batches (cur[4], wl - 3, area + 3): "
+                                                            "build org_scan's FL_ICP_NBQ variants only with this path rewritten to match");
           const float4 *row0 = stage + (v_lo - V0) * W + (u_lo - U0);
           if (nbw == 1) {                                      // every lane's window is at most 4 wide: one batch per row
             for (int dv = 0; dv < maxh; ++dv) {
@@ -1415,7 +1552,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     // the 15 scalars of each row into double-buffered LDS tiles, wave 0 adds the previous tile
     // in row order -- getMean (:8-25) and the covariance loop (:731-735) as 15 float32 chains.
     constexpr int TQ = parity ? SH::TQ : BS;
-    const int slot = parity ? SH::producer_slot() : (int)threadIdx.x;
+    const int slot = parity ? S.producer_slot() : (int)threadIdx.x;
+    const int clane = parity ? S.chain_lane() : -1;      // lane of this thread in the chain wave, or -1
     const int ntiles = (parity || index_pairs) ? (rows + TQ - 1) / TQ : 0;
     float acc = 0.0f;                                    // chain accumulator of lane k < 15 of wave 0
     if (parity && iter > 1) {
@@ -1464,13 +1602,13 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         __builtin_amdgcn_s_waitcnt(0xC07F);                // s_waitcnt lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
       };
-      const bool chain_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0;
+      const bool chain_wave = __builtin_amdgcn_readfirstlane(clane) >= 0;
       if (chain_wave) {
         // the chain wave's own loop: one barrier per tile like the producers' below
         CH_STAMP_BEGIN;
         for (int t = 0; t < ntiles; ++t) {
-          if (t > 0 && threadIdx.x < 15)
-            acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+          if (t > 0 && clane < 15)
+            acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][clane], min(TQ, rows - (t - 1) * TQ), acc);
           CH_STAMP(c_add);
           tile_barrier();
           CH_STAMP(c_bar);
@@ -1537,13 +1675,13 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 #pragma unroll
           for (int q = 0; q < 3; ++q) { ds[9 + q] += have_m ? (double)m[q] : 0.0; ds[12 + q] += (double)r[q]; }
         }
-      } else if (t > 0 && threadIdx.x < 15) {
-        acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, rows - (t - 1) * TQ), acc);
+      } else if (t > 0 && clane >= 0 && clane < 15) {
+        acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][clane], min(TQ, rows - (t - 1) * TQ), acc);
       }
       if (parity) __syncthreads();
     }
-    if (parity && ntiles > 0 && threadIdx.x < 15)
-      acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, rows - (ntiles - 1) * TQ), acc);
+    if (parity && ntiles > 0 && clane >= 0 && clane < 15)
+      acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(ntiles - 1) & 1][clane], min(TQ, rows - (ntiles - 1) * TQ), acc);
     kept = block_sum_int(S, kept);
     TSTAMP(3);
     const int ncm = index_pairs ? n_model : kept, ncr = index_pairs ? n_ref : kept;
@@ -1555,7 +1693,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       continue;
     }
     if (mode == FL_ICP_PARITY) {
-      if (threadIdx.x < 15) S.sums[threadIdx.x] = acc;
+      if (clane >= 0 && clane < 15) S.sums[clane] = acc;
       __syncthreads();
     } else {
       double dd[NSUM];
@@ -1843,6 +1981,53 @@ __device__ __forceinline__ void build_tile_order(SH &S, const int *idximg, int c
   __syncthreads();
 }
 
+// ---- which wave chains (256-thread workgroups) ---------------------------------------------------------------------------
+// Four (or five) of these workgroups share a CU, one wave of each on every SIMD, and each has ONE wave that spends the two
+// chain phases issuing a dependent add every 8 cycles: half a SIMD's issue slots.  Were it always wave 0, the SIMD a CU's
+// chain waves land on would be whatever the dispatcher's rotation made it -- two or three on one SIMD as often as not, with
+// that SIMD saturated and its neighbours idle.  So a workgroup books its chain SIMD in a per-CU table (4 x 8-bit counts, keyed
+// by XCC_ID and HW_ID's SE / SH / CU fields): the least booked SIMD among those its waves run on, released at the end.
+// Purely a scheduling choice: which wave adds does not change what is added, or in which order.
+template <class SH>
+__device__ __forceinline__ void chain_elect(SH &S, unsigned *cu_chain)
+{
+  if (threadIdx.x == 0) { S.cw = 0; S.cu_slot = -1; S.cu_simd = 0; }
+  if (SH::NW >= 8 || !FL_ICP_CHAIN_SIMD || !cu_chain) { __syncthreads(); return; }
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: SIMD_ID [5:4], CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+  if ((threadIdx.x & 63) == 0) S.wsimd[threadIdx.x >> 6] = (int)((hw >> 4) & 3u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;   // HW_REG_XCC_ID
+    const int slot = (int)(((xcc << 8) | ((hw >> 8) & 0xffu)) & (FL_CU_TABLE - 1));
+    unsigned have = 0;
+    for (int w = 0; w < SH::NW; ++w) have |= 1u << S.wsimd[w];
+    unsigned old = atomicAdd(&cu_chain[slot], 0u), best_s = 0;
+    for (;;) {
+      unsigned best_c = 256;
+      for (unsigned sd = 0; sd < 4; ++sd) {
+        const unsigned c = (old >> (8 * sd)) & 0xffu;
+        if (((have >> sd) & 1u) && c < best_c) { best_c = c; best_s = sd; }
+      }
+      if (best_c >= 255u) { best_s = 4; break; }                            // a stale table: do not book
+      const unsigned seen = atomicCAS(&cu_chain[slot], old, old + (1u << (8 * best_s)));
+      if (seen == old) break;
+      old = seen;
+    }
+    if (best_s < 4) {
+      S.cu_slot = slot;
+      S.cu_simd = (int)best_s;
+      for (int w = SH::NW - 1; w >= 0; --w)
+        if (S.wsimd[w] == (int)best_s) S.cw = w;
+    }
+  }
+  __syncthreads();
+}
+template <class SH>
+__device__ __forceinline__ void chain_release(SH &S, unsigned *cu_chain)
+{
+  if (threadIdx.x == 0 && cu_chain && S.cu_slot >= 0) { atomicSub(&cu_chain[S.cu_slot], 1u << (8 * S.cu_simd)); S.cu_slot = -1; }
+}
+
 // waves per SIMD a kernel instance is compiled for: the 256-thread one shares a CU with up to ICP_MODE_WPE - 1 others,
 // a 1024-thread workgroup is 4 waves per SIMD by itself
 #define ICP_WPE(MODE, BS) ((BS) == ICP_BS_SMALL ? ICP_MODE_WPE(MODE) : (BS) / 256)
@@ -1857,6 +2042,7 @@ __global__ __launch_bounds__(BS) void k_icp_clouds(IcpArgs a)
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
   const OrgGeom none = {0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  chain_elect(S, nullptr);
   icp_run<MODE, false>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp, none);
 }
 
@@ -1943,6 +2129,7 @@ void k_icp_pipeline(IcpArgs a)
       return;
     }
   }
+  chain_elect(S, a.cu_chain);                            // (behind the last early return: what is booked here is released below)
   float *rimg = (float *)(wsb + L.sref);                  // image of 12-byte points, then the image of their indices (16 bytes per pixel in all)
   const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod,
                              MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr, rimg,
@@ -1959,7 +2146,7 @@ void k_icp_pipeline(IcpArgs a)
     // (coalesced 12-byte loads) into the LDS tiles, lanes 0..5 of wave 0 add the previous tile
     {
       constexpr int TQ = SH::TQ;
-      const int slot = SH::producer_slot(), ntiles = (np + TQ - 1) / TQ;
+      const int slot = S.producer_slot(), clane = S.chain_lane(), ntiles = (np + TQ - 1) / TQ;
       float acc = 0.0f;
       for (int t = 0; t < ntiles; ++t) {
         if (slot >= 0) {
@@ -1969,14 +2156,14 @@ void k_icp_pipeline(IcpArgs a)
           float (*tile)[SH::TS] = S.prod[t & 1];
           tile[0][slot] = m3.x; tile[1][slot] = m3.y; tile[2][slot] = m3.z;
           tile[3][slot] = r3.x; tile[4][slot] = r3.y; tile[5][slot] = r3.z;
-        } else if (t > 0 && threadIdx.x < 6) {
-          acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][threadIdx.x], min(TQ, np - (t - 1) * TQ), acc);
+        } else if (t > 0 && clane >= 0 && clane < 6) {
+          acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(t - 1) & 1][clane], min(TQ, np - (t - 1) * TQ), acc);
         }
         __syncthreads();
       }
-      if (ntiles > 0 && threadIdx.x < 6)
-        acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(ntiles - 1) & 1][threadIdx.x], min(TQ, np - (ntiles - 1) * TQ), acc);
-      if (threadIdx.x < 6) S.sums[threadIdx.x] = acc;
+      if (ntiles > 0 && clane >= 0 && clane < 6)
+        acc = chain_tile<SH::CHAIN_NBUF>(S.prod[(ntiles - 1) & 1][clane], min(TQ, np - (ntiles - 1) * TQ), acc);
+      if (clane >= 0 && clane < 6) S.sums[clane] = acc;
     }
     __syncthreads();
     for (int k = 0; k < 3; ++k) { mc[k] = S.sums[k]; rc[k] = S.sums[3 + k]; }
@@ -2004,6 +2191,7 @@ void k_icp_pipeline(IcpArgs a)
   }
   __syncthreads();
   icp_run<MODE, true>(S, wsb, L, np, np, a.it_thr, a.dmt, a.ddt, &res->det.icp, og);      // :228
+  chain_release(S, a.cu_chain);
   if (threadIdx.x == 0) {
     const fl_icp_result &ic = res->det.icp;
     float Rt[3];
@@ -2150,8 +2338,20 @@ static_assert(sizeof(IcpSharedT<ICP_BS_WIDE>) + 16 <= 160 * 1024, "IcpSharedT<10
 template <int BS, typename K>
 static int icp_launch_one(fl_context *ctx, K kern, int n_jobs, const IcpArgs &a)
 {
+#ifdef FL_ICP_LDS_PAD                                      // dev builds: extra dynamic LDS per workgroup = fewer workgroups per CU (occupancy experiment)
+  const size_t lds = ((sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15) + (BS == ICP_BS_SMALL ? (size_t)(FL_ICP_LDS_PAD) : 0);
+#else
   const size_t lds = (sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15;
-  FL_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
+  {                                                        // the attribute is set once per kernel and device, not per launch
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done.count({(const void *)kern, ctx->device})) {
+      FL_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done.insert({(const void *)kern, ctx->device});
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(n_jobs), dim3(BS), lds, ctx->stream, a);
   FL_HIP(ctx, hipGetLastError());
   return FL_OK;
@@ -2159,28 +2359,21 @@ static int icp_launch_one(fl_context *ctx, K kern, int n_jobs, const IcpArgs &a)
 // Workgroup width by batch size: with no more jobs than CUs every job runs alone on its CU whatever its width, so it
 // gets the 1024-thread kernel; two rounds of it still beat two 256-thread workgroups per CU (measured, ICP ms per launch,
 // 1024- vs 256-thread: 256 jobs 3.6 / 6.8, 384: 6.4 / 7.2, 512: 6.8 / 7.7, 768: 10.0 / 8.9, 1024: 13.2 / 11.1).
-// FL_ICP_WIDE=0/1 forces one or the other (dev knob)
+// option icp_wide = 0 / 1 forces one or the other (fl_context_set_option)
 static bool icp_wide(fl_context *ctx, int n_jobs)
 {
-  const char *env = getenv("FL_ICP_WIDE");
-  if (env && env[0] == '0') return false;
-  if (env && env[0] == '1') return true;
-  int cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  return n_jobs <= 2 * cus;
+  if (ctx->opt.icp_wide == 0) return false;
+  if (ctx->opt.icp_wide == 1) return true;
+  return n_jobs <= 2 * ctx->cus;
 }
 // Workgroups per CU of the 256-thread parity kernel: whichever of 4 and 5 needs fewer rounds by the measured cost of a full
 // round (5 per CU: about 1.25 x the time of 4 per CU for 1.25 x the frames -- the 96-VGPR build spills more; round 3, jobs
 // dealt longest first, ICP ms per launch at 4 / 5 per CU: 2560 frames 24.9 / 24.0, 3840: 33.4 / 33.2, 4096: 35.0 / 36.5,
-// 5120: 46.7 / 47.7, 6144: 56.0 / 58.5).  FL_ICP_OCC=4/5 forces one (dev knob).
+// 5120: 46.7 / 47.7, 6144: 56.0 / 58.5).  Option icp_occ = 4 / 5 forces one (fl_context_set_option).
 static int icp_small_wpe(fl_context *ctx, int n_jobs)
 {
-  const char *env = getenv("FL_ICP_OCC");
-  if (env && (env[0] == '4' || env[0] == '5')) return env[0] - '0';
-  int cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  if (ctx->opt.icp_occ == 4 || ctx->opt.icp_occ == 5) return (int)ctx->opt.icp_occ;
+  const int cus = ctx->cus;
   const int r4 = (n_jobs + 4 * cus - 1) / (4 * cus), r5 = (n_jobs + 5 * cus - 1) / (5 * cus);
   return 1.25 * r5 < 1.0 * r4 ? 5 : 4;
 }
@@ -2311,6 +2504,7 @@ extern "C" int fl_detection(fl_context *ctx, const uint16_t *model_depth, const 
   a.job.model_depth = dm;
   a.job.scene_depth = dsn;
   a.results = dres;
+  a.cu_chain = ctx->d_cu_chain;
   rc = icp_launch(ctx, 1, a);
   if (rc) return rc;
   fl_recognition_result *hres = nullptr;
@@ -2361,6 +2555,7 @@ int fl_launch_detection_topk(fl_detector *det, int n_frames, int k, const fl_int
   a.poses = det->d_poses;
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = d_results;
+  a.cu_chain = ctx->d_cu_chain;
   return icp_launch(ctx, n_frames * k, a);
 }
 
@@ -2399,7 +2594,19 @@ int fl_launch_detection_jobs(fl_detector *det, int n_jobs, const FlRefineJob *d_
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = det->d_results;
   a.jobs = d_jobs;
+  a.cu_chain = ctx->d_cu_chain;
   return icp_launch(ctx, n_jobs, a);
+}
+
+// once per detector (fl_detector_finalize): the job-order buffer and k_icp_order's LDS size, so that no launch path allocates
+// (an implicit device synchronisation) or sets function attributes
+int fl_icp_prepare(fl_detector *det)
+{
+  fl_context *ctx = det->ctx;
+  if (det->max_batch > 4 * ctx->cus && det->max_batch <= ICP_ORDER_MAX && !det->d_icp_order)
+    FL_HIP(ctx, hipMalloc((void **)&det->d_icp_order, sizeof(int) * 2 * (size_t)det->max_batch));
+  FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * ICP_ORDER_MAX)));
+  return FL_OK;
 }
 
 int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *p,
@@ -2434,18 +2641,13 @@ int fl_launch_detection_batch(fl_detector *det, int n_frames, const fl_intrinsic
   a.poses = det->d_poses;
   a.depth_ptrs = det->d_depth_ptrs;
   a.results = det->d_results;
-  // more jobs than the chip has slots: deal them longest first (see k_icp_order); FL_ICP_ORDER=0 keeps the frame order (dev knob)
-  int cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-  const char *env = getenv("FL_ICP_ORDER");
-  if (n_frames > 4 * cus && n_frames <= ICP_ORDER_MAX && !(env && env[0] == '0')) {
-    if (!det->d_icp_order) FL_HIP(ctx, hipMalloc((void **)&det->d_icp_order, sizeof(int) * 2 * (size_t)det->max_batch));
+  a.cu_chain = ctx->d_cu_chain;
+  // more jobs than the chip has slots: deal them longest first (see k_icp_order); option icp_order = 0 keeps the frame order
+  if (n_frames > 4 * ctx->cus && n_frames <= ICP_ORDER_MAX && det->d_icp_order && ctx->opt.icp_order != 0) {
     int *d_size = det->d_icp_order + det->max_batch;
     hipLaunchKernelGGL(k_icp_count, dim3(n_frames), dim3(256), 0, ctx->stream, a, d_size);
     int m = 1;
     while (m < n_frames) m <<= 1;
-    FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * ICP_ORDER_MAX)));
     hipLaunchKernelGGL(k_icp_order, dim3(1), dim3(1024), sizeof(unsigned long long) * (size_t)m, ctx->stream, (const int *)d_size, n_frames,
                        det->d_icp_order);
     FL_HIP(ctx, hipGetLastError());

@@ -8,6 +8,7 @@
 #include "../../include/fealess_hip.h"
 
 #define FL_WAVE 64
+#define FL_CU_TABLE 4096              // entries of fl_context::d_cu_chain: (XCC_ID << 8) | HW_ID[15:8]
 
 struct fl_context {
   int device = 0;
@@ -19,6 +20,21 @@ struct fl_context {
   size_t scratch_bytes = 0;
   void *pinned = nullptr;       // small pinned host buffer for result read-back
   size_t pinned_bytes = 0;
+  int cus = 256;                // multiProcessorCount of the device (launch heuristics), read once
+  // per-CU bookings of the ICP kernel's chain waves (IcpSharedT::cw): 4 x 8-bit counts per compute unit, zeroed once
+  unsigned *d_cu_chain = nullptr;
+  // Development / comparison switches (fl_context_set_option).  Speed only: results are identical whatever they hold.
+  // Initial values come from the environment ONCE, when the context is created; no launch path reads the environment.
+  struct Options {
+    long scan_prune = 1;        // FL_SCAN_PRUNE: k_scan's exact pruning
+    long scan_prune_mid = -1;   // FL_SCAN_PRUNE_MID: bit mask of the 8-feature groups after which a modality checks the bound (-1: built-in)
+    long icp_wide = -1;         // FL_ICP_WIDE: -1 by batch size, 0 / 1 force the 256- / 1024-thread ICP kernel
+    long icp_occ = 0;           // FL_ICP_OCC: 0 by batch size, 4 / 5 force the 256-thread parity kernel built for 4 / 5 workgroups per CU
+    long icp_order = 1;         // FL_ICP_ORDER: ICP jobs dealt longest first
+    long eager_frontend = 0;    // FL_EAGER_FRONTEND: finer pyramid levels in full before the scan (read by fl_detector_finalize)
+    long dev_poison = 0;        // FL_DEV_POISON: fill what the lazy path leaves uncomputed with 0xFF (read by fl_detector_finalize)
+    long ws_pad = 0;            // FL_DEV_WS_PAD: extra bytes of frame workspace stride (read by fl_detector_finalize)
+  } opt;
   int detectors = 0;            // live fl_detector objects on this context
   bool destroy_pending = false; // fl_context_destroy was called while detectors were alive: the last one releases the context
 };
@@ -217,6 +233,7 @@ int fl_launch_resize_linear_bgr8(fl_context *ctx, const uint8_t *src, int sw, in
 int fl_launch_resize_linear_u16(fl_context *ctx, const uint16_t *src, int sw, int sh, uint16_t *dst, int dw, int dh);
 // icp
 size_t fl_icp_ws_bytes(int n_pts_max);
+int fl_icp_prepare(fl_detector *det);      // fl_detector_finalize: job-order buffer, function attributes
 int fl_launch_detection_topk(fl_detector *det, int n_frames, int k, const fl_intrinsics *K, const fl_recognition_params *p,
                              const uint16_t *depth, size_t depth_stride, uint8_t *ws, fl_recognition_result *d_results);
 size_t fl_icp_ws_bytes(int n_pts_max);

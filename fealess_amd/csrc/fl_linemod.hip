@@ -886,8 +886,8 @@ static int launch_scan_refine_sort(fl_detector *det, int n_frames, float thresho
     a.T = g.T;
     a.cap = det->cap;
     a.threshold = threshold;
-    { const char *e = getenv("FL_SCAN_PRUNE"); a.prune = !(e && e[0] == '0'); }
-    { const char *e = getenv("FL_SCAN_PRUNE_MID"); a.prune_mid = e ? (unsigned)strtoul(e, nullptr, 16) : FL_SCAN_PRUNE_MID; }
+    a.prune = ctx->opt.scan_prune != 0;                   // development switches (fl_context_set_option)
+    a.prune_mid = ctx->opt.scan_prune_mid >= 0 ? (unsigned)ctx->opt.scan_prune_mid : FL_SCAN_PRUNE_MID;
     a.dbg = dbg;
     a.dbg_first = dbg_first;
     a.dbg_count = dbg_count;
@@ -1029,6 +1029,14 @@ extern "C" int fl_detector_grow_candidates(fl_detector *det, int n_frames, int *
   if (!det || n_frames <= 0) return FL_ERR_INVALID;
   fl_context *ctx = det->ctx;
   if (!det->finalized || n_frames > det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "n_frames");
+  if (det->last_batch == 0) {                            // nothing matched yet: no counters to read, just report the capacity
+    if (new_cap) *new_cap = det->cap;
+    return FL_OK;
+  }
+  // only the last batch's frames have counters that mean anything: a flag left by an earlier, larger batch must not trigger a
+  // stream sync, a free and a re-layout of every frame workspace
+  if (n_frames > det->last_batch)
+    return fl_set_error(ctx, FL_ERR_STATE, "n_frames %d > the %d frames of the last batch", n_frames, det->last_batch);
   FL_HIP(ctx, hipSetDevice(ctx->device));
   int needed = 0;
   int rc = fl_overflow_needed(det, n_frames, &needed);

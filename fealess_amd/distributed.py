@@ -138,7 +138,9 @@ def template_sharded_recognize(n_frames, k, n_templates, world, rank, local_topk
       allreduce_sum(array)    -> the elementwise sum over ranks of an INT32 numpy array (every rank gets it)
       grow()                  -> (optional) grow this rank's candidate buffers to what its last batch needs
                                  (fl_detector_grow_candidates); called on EVERY rank when any rank overflowed -- the flag is
-                                 in the gathered records, so all ranks agree -- after which the step runs again
+                                 in the gathered records, so all ranks agree -- after which the step runs again.  May raise
+                                 (hard cap, no memory): the failure is all-reduced, every rank stops retrying, and the
+                                 frames concerned are reported as TOPK_OVERFLOW
 
     Recognition() only ever uses matches[0] (obj_reco_lmicp.cpp:111), which is the best of the ranks' best records
     (best_of_ranks); full_lists=True also merges the whole lists as one Detector::match would order them
@@ -153,7 +155,17 @@ def template_sharded_recognize(n_frames, k, n_templates, world, rank, local_topk
         best = best_of_ranks(gathered)
         if not (best["template_id"] == TOPK_OVERFLOW).any() or grow is None or attempt == max_attempts:
             break
-        grow()                                                 # every rank: same records, same decision
+        # every rank: same records, same decision to grow.  The OUTCOME of growing is made collective too: a rank whose
+        # buffers cannot grow (hard cap, out of memory: fl_detector_grow_candidates -> FL_ERR_OVERFLOW) must not leave the
+        # others waiting in the next all-gather, so the failure count is summed over the ranks and everyone stops together;
+        # the frames concerned stay TOPK_OVERFLOW (found = 0).
+        failed = 0
+        try:
+            grow()
+        except Exception:                                      # noqa: BLE001 -- whatever it was, the ranks must agree on it
+            failed = 1
+        if int(np.asarray(allreduce_sum(np.array([failed], np.int32))).reshape(-1)[0]) != 0:
+            break
     n_out = None
     ok = best["template_id"] != TOPK_OVERFLOW
     if full_lists:

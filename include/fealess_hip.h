@@ -51,10 +51,14 @@ typedef enum { FL_MEM_HOST = 0, FL_MEM_DEVICE = 1 } fl_mem;
  *                   so results are bit-identical to the reference's arithmetic (ICP.cpp:8-25,
  *                   731-735, 68-111).  Default.
  *   FL_ICP_FAST   : the same sums as parallel reductions (float32 per-thread partials of ~60
- *                   terms, fp64 tree across the workgroup, rounded once to float32): closer to the
- *                   exact sums than the reference's float32 chains, not bit-identical to them.
- *                   About 6 % quicker than FL_ICP_PARITY (15.8 vs 16.8 ms per 1280 frames): the
- *                   exact nearest-neighbour search dominates both.
+ *                   terms, fp64 tree across the workgroup, rounded once to float32): within 1e-4
+ *                   of the EXACT sums' pose, not bit-identical to the reference's float32 chains.
+ *                   Against the reference's float32 result the final pose differs by up to 1.1e-4
+ *                   (R) / 1.1e-4 (T, relative to the object's distance) on 15 k-point clouds --
+ *                   that is the reference's own summation noise (its float32 result is that far
+ *                   from the exact sums); tests/test_gpu_icp.py asserts <= 2.5e-4 and "no farther
+ *                   than the float32 result is from the exact sums".  Use FL_ICP_PARITY where the
+ *                   1e-4 bar against the reference matters.  Timings of both: bench.py `icp_fast`.
  *   FL_ICP_POINT_TO_PLANE : opt-in extension with NO counterpart in the reference (SURVEY.md
  *                   section 8f rank 4): every iteration (the first included) pairs each model point
  *                   with its exact nearest reference point, gates the pair at distance
@@ -129,6 +133,18 @@ const char *fl_last_error(const fl_context *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL restores the context's own */
 int  fl_context_set_stream(fl_context *ctx, void *hip_stream);
 int  fl_context_synchronize(fl_context *ctx);
+/* Development / comparison switches.  They change how the work is scheduled, never a result: "scan_prune" (1; 0 = the scan adds
+ * every feature everywhere, as the reference does), "scan_prune_mid" (bit mask of the 8-feature groups after which a modality
+ * checks the pruning bound; -1 = built-in), "icp_wide" (-1 = by batch size; 0 / 1 force the 256- / 1024-thread ICP workgroup),
+ * "icp_occ" (0 = by batch size; 4 / 5 force the 256-thread kernel built for that many workgroups per CU), "icp_order" (1 = ICP
+ * jobs dealt longest first; 0 = frame order), and -- sampled by fl_detector_finalize -- "eager_frontend" (1 = finer pyramid
+ * levels in full before the scan, the reference's order), "dev_poison" (1 = what the lazy path leaves uncomputed is filled
+ * with 0xFF), "ws_pad" (extra bytes of frame-workspace stride).  Their INITIAL values are read once from the environment
+ * when the context is created (FL_SCAN_PRUNE, FL_SCAN_PRUNE_MID (hex), FL_ICP_WIDE, FL_ICP_OCC, FL_ICP_ORDER,
+ * FL_EAGER_FRONTEND, FL_DEV_POISON, FL_DEV_WS_PAD); nothing reads the environment after that, so a variable set in a host
+ * process later on changes nothing.  Unknown names: FL_ERR_INVALID. */
+int  fl_context_set_option(fl_context *ctx, const char *name, long value);
+int  fl_context_get_option(const fl_context *ctx, const char *name, long *value);
 
 /* ---- detector = cup_linemod::Detector state resident in HBM -------------------------------- */
 /* Detector::Detector(modalities, T_pyramid) (linemod.cpp:1348-1354). modalities is 1 or 2:

@@ -4,10 +4,17 @@
 // otherwise write by hand.  Every function keeps the reference's name, argument list and
 // error behaviour and cites what it replaces:
 //   * fealess_cv::readLinemod            linemod/linemod_if.h:15 (cv::Ptr<Detector> readLinemod(const std::string&))
+//   * fealess_cv::writeLinemod           linemod/linemod_if.h:17 / linemod_if.cpp:49-63
+//   * fealess_cv::drawResponse (x2)      linemod/linemod_if.h:19-23 / linemod_if.cpp:65-150 (host-side drawing, no GPU work)
 //   * fealess_cv::Detector::match        linemod/linemod.hpp:324-327 / linemod.cpp:1356-1441
 //   * fealess_cv::detection              ICP/detection.h:9-11 / ICP/detection.cpp:11-254
 //   * fealess_cv::icpCloudToCloud_Ex     ICP/ICP.h:165-172 / ICP/ICP.cpp:617-809
 //   * fealess_cv::depthTo3d              ICP/depth_to_3d.h:12-13 / depth_to_3d.cpp:244-269
+// The reference's own names: unless FEALESS_CV_NO_REFERENCE_NAMES is defined, the header also declares them where the
+// reference has them -- cup_linemod::{Detector, Match, Template, Feature}, the global readLinemod / writeLinemod /
+// drawResponse / detection / icpCloudToCloud_Ex and cup_d2pc::depthTo3d -- as aliases of the fealess_cv ones, so a
+// translation unit that included "linemod_if.h", "ICP.h", "detection.h" and "depth_to_3d.h" compiles against this header
+// unchanged (define the macro where both sets of headers have to coexist in one translation unit).
 // Build: -I include -I fealess_amd/cadreco, link libfealess_hip.so and libcadreco_hip.so (the latter for the
 // linemod_templates.yml reader).  There is no OpenCV in the build image, so this header is checked for syntax against
 // a minimal stand-in of <opencv2/core.hpp> (tests/dropin/opencv_stub, tests/test_dropin_cpu.py) and has not been run.
@@ -15,6 +22,7 @@
 #define FEALESS_OPENCV_ADAPTER_HPP
 
 #include <opencv2/core.hpp>
+#include <opencv2/imgproc.hpp>      // cv::circle (drawResponse)
 
 #include <algorithm>
 #include <map>
@@ -125,6 +133,7 @@ class Detector {
     return 0;
   }
 
+  const fealess::DetectorFile &file() const { return file_; }     // what writeLinemod writes back
   fl_detector *handle() const { return det_; }       // for fl_recognize_* / multi-GPU calls on the same bank
   fl_context *context() const { return ctx_; }
 
@@ -181,6 +190,49 @@ inline cv::Ptr<Detector> readLinemod(const std::string &filename, int device = 0
   }
   std::sort(d->class_ids_.begin(), d->class_ids_.end());
   return d;
+}
+
+// writeLinemod (linemod_if.h:17, linemod_if.cpp:49-63): Detector::write + writeClass for every class into one
+// FileStorage YAML (linemod.cpp:1696-1794) -- the file readLinemod reads
+inline void writeLinemod(const cv::Ptr<Detector> &detector, const std::string &filename)
+{
+  if (!detector || !fealess::WriteLinemod(detector->file(), filename)) CV_Error(cv::Error::StsError, "writeLinemod: cannot write the file");
+}
+
+// drawResponse (linemod_if.h:19-20, linemod_if.cpp:65-88): one circle of radius T / 2 per feature, the colour by modality
+inline void drawResponse(const std::vector<fealess::Template> &templates, int num_modalities, cv::Mat &dst, cv::Point offset, int T)
+{
+  static const cv::Scalar COLORS[5] = {cv::Scalar(0, 140, 255), cv::Scalar(0, 255, 0), cv::Scalar(0, 255, 255), cv::Scalar(0, 140, 255),
+                                       cv::Scalar(0, 0, 255)};                       // CV_RGB(r, g, b) = Scalar(b, g, r)
+  for (int m = 0; m < num_modalities; ++m)
+    for (size_t i = 0; i < templates[(size_t)m].features.size(); ++i) {
+      const fealess::Feature &f = templates[(size_t)m].features[i];
+      cv::circle(dst, cv::Point(f.x + offset.x, f.y + offset.y), T / 2, COLORS[m], 2);
+    }
+}
+// drawResponse with the rendered template pasted in first (linemod_if.h:22-23, linemod_if.cpp:90-150): the bounding box of
+// current_template's non-black pixels (rows in min_x .. max_x, columns in min_y .. max_y, the reference's naming), grown by
+// one at its far edges, is copied to dst at `offset` wherever it is non-black; then the circles as above
+inline void drawResponse(const std::vector<fealess::Template> &templates, int num_modalities, cv::Mat &dst, cv::Point offset, int T,
+                         cv::Mat current_template)
+{
+  int min_x = 1000, min_y = 1000, max_x = 0, max_y = 0;
+  for (int i = 0; i < current_template.rows; ++i)
+    for (int j = 0; j < current_template.cols; ++j) {
+      const cv::Vec3b &p = current_template.at<cv::Vec3b>(i, j);
+      if (p[0] != 0 || p[1] != 0 || p[2] != 0) {
+        min_x = std::min(min_x, i); max_x = std::max(max_x, i);
+        min_y = std::min(min_y, j); max_y = std::max(max_y, j);
+      }
+    }
+  if (max_x < current_template.rows - 1) max_x += 1;
+  if (max_y < current_template.cols - 1) max_y += 1;
+  for (int i = min_x; i < max_x; ++i)
+    for (int j = min_y; j < max_y; ++j) {
+      const cv::Vec3b &p = current_template.at<cv::Vec3b>(i, j);
+      if (p[0] != 0 || p[1] != 0 || p[2] != 0) dst.at<cv::Vec3b>(i - min_x + offset.y, j - min_y + offset.x) = p;
+    }
+  drawResponse(templates, num_modalities, dst, offset, T);
 }
 
 // one context for the free functions below (the reference's are stateless)
@@ -245,4 +297,22 @@ inline void depthTo3d(cv::InputArray depth_in, cv::InputArray K_in, cv::OutputAr
 }
 
 }  // namespace fealess_cv
+
+#ifndef FEALESS_CV_NO_REFERENCE_NAMES
+// the names a CadReco translation unit already uses (linemod.hpp, linemod_if.h, ICP.h, detection.h, depth_to_3d.h)
+namespace cup_linemod {
+using fealess_cv::Detector;
+using fealess_cv::Match;
+typedef fealess::Template Template;
+typedef fealess::Feature Feature;
+}  // namespace cup_linemod
+using fealess_cv::readLinemod;
+using fealess_cv::writeLinemod;
+using fealess_cv::drawResponse;
+using fealess_cv::detection;
+using fealess_cv::icpCloudToCloud_Ex;
+namespace cup_d2pc {
+using fealess_cv::depthTo3d;
+}  // namespace cup_d2pc
+#endif
 #endif  // FEALESS_OPENCV_ADAPTER_HPP

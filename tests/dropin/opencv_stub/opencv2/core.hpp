@@ -19,6 +19,9 @@ struct Size { int width, height; bool operator==(const Size &o) const; };
 template <typename T> struct Rect_ { T x, y, width, height; };
 struct Matx33f { float val[9]; };
 struct Vec3f { float val[3]; };
+struct Vec3b { unsigned char val[3]; unsigned char &operator[](int i); const unsigned char &operator[](int i) const; };
+struct Point { int x, y; Point(); Point(int x_, int y_); };
+struct Scalar { double val[4]; Scalar(); Scalar(double a, double b, double c); };
 class Mat {
  public:
   Mat();

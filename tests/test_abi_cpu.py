@@ -54,6 +54,28 @@ def test_product_does_not_touch_the_oracle():
                 assert "liboracle" not in txt and "oracle_py" not in txt and "fealess_oracle.h" not in txt, (dirpath, f)
 
 
+def test_search_bound_packing_saturates():
+    """The ICP kernel keeps its per-point search bound as the top 16 bits of a float32, rounded UP (bnd_st / bnd_ld in
+    fl_icp.hip; the packing is host + device code, exported as fl_dev_bnd_pack for this check).  A stored bound may be larger
+    than the value, never smaller; +inf stays +inf, FLT_MAX rounds up to +inf, and EVERY NaN payload -- also the ones whose low
+    mantissa bits would carry into the exponent or the sign -- is stored as a NaN ("no bound"), never as a small number."""
+    lib = L.load()
+    lib.fl_dev_bnd_pack.restype = C.c_uint
+    lib.fl_dev_bnd_pack.argtypes = [C.c_uint]
+
+    def unpack(p):
+        return np.array([p << 16], np.uint32).view(np.float32)[0]
+
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.uniform(0, 1e4, 2000), 10.0 ** rng.uniform(-30, 38, 2000), [0.0, 1.0, 3.4028235e38, 65536.0, 1e-45]]).astype(np.float32)
+    for v in vals:
+        got = unpack(lib.fl_dev_bnd_pack(int(np.array([v], np.float32).view(np.uint32)[0])))
+        assert got >= v and (np.isinf(got) or got <= v * np.float32(1.008) + np.float32(1e-38)), (v, got)
+    assert np.isinf(unpack(lib.fl_dev_bnd_pack(0x7F800000))) and np.isinf(unpack(lib.fl_dev_bnd_pack(0x7F7FFFFF)))
+    for bits in (0x7FC00000, 0x7FFFFFFF, 0x7FFF0001, 0x7F800001, 0x7F80FFFF, 0xFFC00000, 0xFFFFFFFF, 0xFFFF0001, 0xFF800001, 0x80000000, 0xBF800000):
+        assert np.isnan(unpack(lib.fl_dev_bnd_pack(bits))), hex(bits)     # NaNs and (impossible) negative bounds: no bound
+
+
 def test_lm_label_stride_matches_oracle(oracle):
     lib = L.load()
     for (w, h, T) in [(640, 480, 5), (320, 240, 8), (1280, 720, 5), (320, 180, 4), (64, 48, 8)]:

@@ -49,14 +49,15 @@ def test_depth_to_3d_bit_exact(ctx, oracle, w, h, K):
 
 
 @pytest.fixture(params=["1024", "256", "256x5"])
-def width(request, monkeypatch):
+def width(request, ctx):
     """Every build of the ICP kernels: the library picks the 1024-thread workgroup for batches of up to two jobs per CU (with the
     search running ahead of the dist_mean chain) and a 256-thread one beyond, compiled for 4 or for 5 workgroups per CU (whichever
-    finishes the batch sooner); FL_ICP_WIDE and FL_ICP_OCC force any of them for any batch."""
-    monkeypatch.setenv("FL_ICP_WIDE", "1" if request.param == "1024" else "0")
-    if request.param == "256x5":
-        monkeypatch.setenv("FL_ICP_OCC", "5")
-    return request.param
+    finishes the batch sooner); the options icp_wide and icp_occ (fl_context_set_option) force any of them for any batch."""
+    ctx.set_option("icp_wide", 1 if request.param == "1024" else 0)
+    ctx.set_option("icp_occ", 5 if request.param == "256x5" else 0)
+    yield request.param
+    ctx.set_option("icp_wide", -1)
+    ctx.set_option("icp_occ", 0)
 
 
 @pytest.mark.parametrize("seed,n,it", [(1, 6000, 20), (2, 1500, 10), (3, 12000, 6)])
@@ -387,8 +388,8 @@ def test_point_to_plane_recognition_improves_the_pose(ctx, oracle):
 
 # ---- lazy fine levels: fl_recognize_* quantise / spread the finer levels only in the tiles the candidates touch ----
 @pytest.mark.parametrize("levels,T", [(2, [5, 8]), (3, [5, 8, 4])])
-def test_lazy_fine_levels_equal_eager_and_oracle(ctx, oracle, levels, T, monkeypatch):
-    """Same results with the finer levels computed lazily (default) and eagerly (FL_EAGER_FRONTEND=1), for frames
+def test_lazy_fine_levels_equal_eager_and_oracle(ctx, oracle, levels, T):
+    """Same results with the finer levels computed lazily (default) and eagerly (option eager_frontend = 1), for frames
     whose object sits mid-image, is pushed against each border (patches that leave their linear memory mark the whole
     frame) or is absent; conftest.py poisons everything outside the marked tiles."""
     sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=levels, seed=11, n_views=5, n_random=25)
@@ -400,11 +401,11 @@ def test_lazy_fine_levels_equal_eager_and_oracle(ctx, oracle, levels, T, monkeyp
     frames_b.append(np.full_like(sc["bgr"], 90)); frames_d.append(np.full_like(sc["depth"], 1200))
     results = {}
     for mode in ("lazy", "eager"):
-        if mode == "eager":
-            monkeypatch.setenv("FL_EAGER_FRONTEND", "1")
+        ctx.set_option("eager_frontend", 1 if mode == "eager" else 0)      # sampled by fl_detector_finalize
         det = api.Detector(ctx, 2, T)
         det.add_class(sc["bank"])
         det.finalize(640, 480, max_batch=len(frames_b))
+        ctx.set_option("eager_frontend", 0)
         results[mode] = det.recognize_batch(frames_b, frames_d, sc["K"], 70.0, 10, 0.5, 0.01)
         t = det.stage_times()
         assert (t["lazy_frontend_ms"] > 0) == (mode == "lazy")
@@ -598,11 +599,11 @@ def test_refine_matches_argument_checks_and_result(ctx, oracle):
     det.close()
 
 
-def test_large_batch_jobs_dealt_longest_first_keep_their_results(ctx, oracle, monkeypatch):
+def test_large_batch_jobs_dealt_longest_first_keep_their_results(ctx, oracle):
     """A batch above four frames per CU hands the ICP launch its jobs longest first (k_icp_count + k_icp_order: workgroup b
     runs job order[b]).  The order is scheduling only: every frame's result must be what the same frame gives alone, and what
-    the batch gives in frame order (FL_ICP_ORDER=0), bit for bit -- frames of different cloud sizes, so that the order is a
-    real permutation.  Also the exact pruning of the scan (FL_SCAN_PRUNE=0/1): same matches either way."""
+    the batch gives in frame order (option icp_order = 0), bit for bit -- frames of different cloud sizes, so that the order is a
+    real permutation.  Also the exact pruning of the scan (option scan_prune = 0 / 1): same matches either way."""
     import torch
     scenes = [synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=s, n_views=3) for s in (3, 5)]
     sc = scenes[0]
@@ -627,13 +628,13 @@ def test_large_batch_jobs_dealt_longest_first_keep_their_results(ctx, oracle, mo
     single = det.recognize_batch(frames_b, frames_d, sc["K"], 75.0, 8, 0.0, -3.0e38)
     assert sum(r["found"] for r in single) >= 3 and len({r["det"]["n_points"] for r in single if r["found"]}) >= 2
     runs = {}
-    for tag, env in (("longest_first", {}), ("frame_order", {"FL_ICP_ORDER": "0"}), ("unpruned", {"FL_SCAN_PRUNE": "0"})):
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
+    for tag, opts in (("longest_first", {}), ("frame_order", {"icp_order": 0}), ("unpruned", {"scan_prune": 0})):
+        for k_, v_ in opts.items():
+            ctx.set_option(k_, v_)
         det.recognize_submit_device(bp, dp, sc["K"], params)
         runs[tag] = [api.recognition_result_to_dict(r) for r in det.recognize_collect(n)]
-        for k_ in env:
-            monkeypatch.delenv(k_)
+        for k_ in opts:
+            ctx.set_option(k_, 1)
     for tag, res in runs.items():
         for i in range(n):
             e, g = single[order[i]], res[i]

@@ -145,7 +145,7 @@ def test_quirks_overread_oob_and_big_template(ctx, oracle):
     det.close()
 
 
-def test_pruned_scan_when_the_modalities_templates_differ_in_size(ctx, oracle, monkeypatch):
+def test_pruned_scan_when_the_modalities_templates_differ_in_size(ctx, oracle):
     """k_scan stops a (template, chunk) once no position can reach the threshold.  The positions a modality scans end at ITS
     template_positions (linemod.cpp:1152-1160), so with a small colour template and a large depth template there are positions
     that collect from the colour modality alone -- here they are the only candidates, every position the depth modality
@@ -165,9 +165,10 @@ def test_pruned_scan_when_the_modalities_templates_differ_in_size(ctx, oracle, m
     seen = 0
     for thr in (-100.0, 0.0, 20.0, 45.0, 60.0, 100.0):
         exp, n_exp = oracle.match_quantized(qs, w0, h0, T, [bank], thr)
-        for prune in ("1", "0"):
-            monkeypatch.setenv("FL_SCAN_PRUNE", prune)
+        for prune in (1, 0):
+            ctx.set_option("scan_prune", prune)
             got, n_got = det.match_quantized(qs, thr, cap=1 << 16)
+            ctx.set_option("scan_prune", 1)
             assert n_got == n_exp, (thr, prune)
             _assert_matches_equal(got, exp)
         seen += n_exp

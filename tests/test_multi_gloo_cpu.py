@@ -150,6 +150,19 @@ def _worker_recognize(rank, world, port, out_dir):
     b3, _, p3 = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk_overflowing, allgather, refine_checked, allreduce_sum, grow=grow)
     ok = ok and state["grown"] == 1 and state["calls"] == 2          # both ranks grew once and ran the step twice
     ok = ok and b3.tobytes() == best.tobytes() and np.array_equal(p3.view(np.uint32), poses.view(np.uint32))
+    # A rank whose buffers cannot grow (hard cap / out of memory: grow() raises on THAT rank only) must not leave the other
+    # rank waiting in the next all-gather: the outcome of growing is all-reduced, both ranks stop retrying after the same
+    # attempt and report the frame as TOPK_OVERFLOW.
+    state.update(grown=0, calls=0)
+
+    def grow_failing_on_rank1():
+        if rank == 1:
+            raise RuntimeError("fl_detector_grow_candidates: FL_ERR_OVERFLOW (hard cap)")
+
+    b4, _, p4 = D.template_sharded_recognize(len(frames), k, n, world, rank, local_topk_overflowing, allgather, refine_checked, allreduce_sum,
+                                             grow=grow_failing_on_rank1)
+    ok = ok and state["calls"] == 1 and int(b4["template_id"][1]) == D.TOPK_OVERFLOW and not p4[1].any()
+    ok = ok and int(b4["template_id"][0]) == int(best["template_id"][0]) and np.array_equal(p4[0].view(np.uint32), poses[0].view(np.uint32))
     # the pose rows travel as int32 bit patterns: a -0.0 of the owner survives the exchange (a float sum would give +0.0)
     z = np.zeros((1, 17), np.float32)
     if rank == 0:
