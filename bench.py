@@ -62,6 +62,9 @@ def parse():
                     help="--shard templates: the round-2 path (records and poses staged through the host, numpy merge) instead of the device one")
     ap.add_argument("--compare-host-merge", action="store_true",
                     help="--shard templates: also time the host-merge path and report it beside the device path's figure")
+    ap.add_argument("--mg-host", choices=["python", "cxx"], default="python",
+                    help="--shard templates: who drives the collectives -- torch.distributed from Python, or the C++ host "
+                         "libfealess_mg.so (include/fealess_mg.h: ncclAllGather / ncclAllReduce from C++; needs one GPU per rank)")
     ap.add_argument("--verify-sharded", action="store_true",
                     help="--shard templates: rank 0 also runs one detector over the whole bank and checks every frame's result bit for bit")
     ap.add_argument("--no-cpu-baseline", action="store_true")

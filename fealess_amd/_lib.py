@@ -78,6 +78,9 @@ SIGNATURES = {
     "fl_last_error": (C.c_char_p, [_P]),
     "fl_context_set_stream": (_I, [_P, _P]),
     "fl_context_synchronize": (_I, [_P]),
+    "fl_context_get_stream": (_P, [_P]),
+    "fl_context_get_device": (_I, [_P]),
+    "fl_detector_get_context": (_P, [_P]),
     "fl_context_set_option": (_I, [_P, C.c_char_p, C.c_long]),
     "fl_context_get_option": (_I, [_P, C.c_char_p, C.POINTER(C.c_long)]),
     "fl_detector_create": (_I, [_P, _I, _I, C.POINTER(_I), C.POINTER(_P)]),
@@ -131,7 +134,41 @@ SIGNATURES = {
     "fl_frame_counters": (_I, [_P, _I, C.POINTER(C.c_int32)]),
 }
 
+class MgResult(C.Structure):         # include/fealess_mg.h fl_mg_result
+    _fields_ = [("status", C.c_int32), ("found", C.c_int32), ("best", Match), ("pose", C.c_float * 16)]
+
+
+FL_MG_ID_BYTES = 128
+MG_LIB_PATH = os.path.join(_HERE, "mg", "libfealess_mg.so")
+# every symbol include/fealess_mg.h declares (libfealess_mg.so: the C++ multi-GPU host on RCCL)
+MG_SIGNATURES = {
+    "fl_mg_unique_id": (_I, [_P, C.c_size_t]),
+    "fl_mg_create": (_I, [_P, _P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "fl_mg_destroy": (None, [_P]),
+    "fl_mg_last_error": (C.c_char_p, [_P]),
+    "fl_mg_recognize_batch": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_P), _I, C.POINTER(Intrinsics), C.POINTER(RecognitionParams), _P]),
+    "fl_mg_last_stats": (_I, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+}
+
 _lib = None
+_mg_lib = None
+
+
+def load_mg():
+    """Load libfealess_mg.so (links librccl and libfealess_hip.so); raises if it has not been built."""
+    global _mg_lib
+    if _mg_lib is None:
+        load()
+        if not os.path.exists(MG_LIB_PATH):
+            raise RuntimeError(f"{MG_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(MG_LIB_PATH)
+        for name, (res, args) in MG_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _mg_lib = lib
+    return _mg_lib
+
 
 
 def load():

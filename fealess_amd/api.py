@@ -381,6 +381,12 @@ class Detector:
         self.ctx.check(self.lib.fl_recognize_collect(self.h, n, res))
         return res
 
+    def frame_counters(self, frame):
+        """fl_frame_counters: (coarse candidates, matches after sort/unique, overflow flag, marked level-0 tiles or -1)."""
+        out = (C.c_int32 * 4)()
+        self.ctx.check(self.lib.fl_frame_counters(self.h, frame, out))
+        return tuple(int(v) for v in out)
+
     def stage_times(self):
         t = L.StageTimes()
         self.ctx.check(self.lib.fl_last_stage_times(self.h, C.byref(t)))
@@ -423,6 +429,50 @@ class Detector:
     def close(self):
         if self.h:
             self.lib.fl_detector_destroy(self.h)
+            self.h = None
+
+
+class MgGroup:
+    """One rank of a template-sharded group driven by the C++ host (libfealess_mg.so, include/fealess_mg.h): RCCL
+    all-gather of the top-k records, winner selection and refinement on the device, int32 all-reduce of the pose rows."""
+
+    @staticmethod
+    def unique_id():
+        lib = L.load_mg()
+        buf = C.create_string_buffer(L.FL_MG_ID_BYTES)
+        rc = lib.fl_mg_unique_id(buf, L.FL_MG_ID_BYTES)
+        if rc != L.FL_OK:
+            raise FealessError(rc, "fl_mg_unique_id (ncclGetUniqueId) failed")
+        return buf.raw
+
+    def __init__(self, det, unique_id, n_ranks, rank, tid_first, tid_count, k):
+        self.lib = L.load_mg()
+        self.det = det
+        h = C.c_void_p()
+        rc = self.lib.fl_mg_create(det.h, C.c_char_p(unique_id), n_ranks, rank, tid_first, tid_count, k, C.byref(h))
+        if rc != L.FL_OK:
+            raise FealessError(rc, "fl_mg_create (ncclCommInitRank) failed")
+        self.h = h
+
+    def recognize_batch(self, bgr_ptrs, depth_ptrs, K, params, mem=L.FL_MEM_DEVICE):
+        n = len(bgr_ptrs)
+        bp = (C.c_void_p * n)(*bgr_ptrs)
+        dp = (C.c_void_p * n)(*depth_ptrs)
+        k = L.Intrinsics(self.det.w0, self.det.h0, *K)
+        res = (L.MgResult * n)()
+        rc = self.lib.fl_mg_recognize_batch(self.h, n, bp, dp, mem, C.byref(k), C.byref(params), res)
+        if rc != L.FL_OK:
+            raise FealessError(rc, self.lib.fl_mg_last_error(self.h).decode(errors="replace"))
+        return res
+
+    def stats(self):
+        a, g, r = C.c_int32(), C.c_size_t(), C.c_size_t()
+        self.lib.fl_mg_last_stats(self.h, C.byref(a), C.byref(g), C.byref(r))
+        return dict(attempts=a.value, allgather_bytes=g.value, allreduce_bytes=r.value)
+
+    def close(self):
+        if self.h:
+            self.lib.fl_mg_destroy(self.h)
             self.h = None
 
 

@@ -195,6 +195,32 @@ def run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames, cpu_bas
             out = (b, p)
         return out
 
+    # ---- the C++ host (libfealess_mg.so, include/fealess_mg.h): the same step driven from C++ directly on RCCL ----------
+    cxx = getattr(args, "mg_host", "python") == "cxx"
+    mg = None
+    if cxx:
+        if dist is not None and not on_gpu_collectives:
+            raise SystemExit("--mg-host cxx drives RCCL itself: one GPU per rank (no --share-device / gloo rehearsal)")
+        uid = [api.MgGroup.unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)                          # ncclGetUniqueId on rank 0, handed to every rank
+        mg = api.MgGroup(det, uid[0], world, rank, first, count, k)
+        MG_DT = np.dtype([("status", "<i4"), ("found", "<i4"), ("best", MATCH_DTYPE), ("pose", "<f4", 16)])
+
+        def steps_cxx(n):
+            out = None
+            for _ in range(n):
+                res = mg.recognize_batch(bptr, dptr, K, params)
+                host_syncs[0] += mg.stats()["attempts"]                     # one stream synchronisation per attempt
+                a = np.frombuffer(res, dtype=MG_DT)
+                b = a["best"].copy()
+                b["template_id"][a["status"] != 0] = D.TOPK_OVERFLOW
+                p = np.zeros((B, 17), np.float32)
+                p[:, 0] = a["found"]
+                p[:, 1:] = a["pose"]
+                out = (b, p)
+            return out
+
     def sync_all():
         torch.cuda.synchronize(device)
         if dist is not None:
@@ -222,13 +248,16 @@ def run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames, cpu_bas
     if (best0["template_id"] == D.TOPK_OVERFLOW).any():
         raise RuntimeError("a frame's candidate buffers still overflow after growing them")
     sync_all()
-    main_fn = steps_device if device_path else steps_host
+    main_fn = steps_cxx if cxx else (steps_device if device_path else steps_host)
     el, (best, poses), syncs_per_step = timed(main_fn, args.steps, args.warmup)
     if (best["template_id"] == D.TOPK_OVERFLOW).any():
         raise RuntimeError("candidate-buffer overflow inside the timed steps")
-    icp_ms = ev_icp[0].elapsed_time(ev_icp[1]) if device_path else None
+    if cxx:                                                              # a python-driven device step for the ICP launch's HIP events
+        steps_device(1)
+        sync_all()
+    icp_ms = ev_icp[0].elapsed_time(ev_icp[1]) if device_path or cxx else None
     compare = None
-    if device_path and args.compare_host_merge:
+    if (device_path or cxx) and args.compare_host_merge:
         el_h, (best_hm, poses_hm), syncs_h = timed(steps_host, args.steps, 1)
         compare = dict(ms_per_step=round(el_h / args.steps * 1e3, 4), host_syncs_per_step=round(syncs_h, 2),
                        same_result=bool(best_hm.tobytes() == best.tobytes() and np.array_equal(poses_hm.view(np.uint32), poses.view(np.uint32))),
@@ -247,13 +276,16 @@ def run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames, cpu_bas
         res = det.refine_matches(own.tolist(), jobs, K, params) if len(own) else []
         a = np.frombuffer(res, dtype=api.RESULT_DTYPE) if len(own) else None
         iter_bytes = 0.0 if a is None else float((a["det"]["icp"]["iters"].astype(np.float64) * a["det"]["n_points"] * 72)[a["found"] > 0].sum())
-        icp_bytes = iter_bytes + len(own) * 2 * 14 * w * h
+        tpl, _, _ = shard.arrays()
+        LM = shard.levels * shard.modalities
+        crop_px = float(sum(int(tpl[int(t_) * LM]["width"]) * int(tpl[int(t_) * LM]["height"]) for t_, f_ in zip(jobs["template_id"], a["found"]) if f_)) if a is not None else 0.0
+        icp_bytes = iter_bytes + 2 * 14 * crop_px                           # what the fused kernel needs (bench.py: roofline.frac)
         kern = {"k_scan": (times["scan_ms"], times["scan_algorithmic_bytes"]), "k_icp_pipeline": (icp_ms or 0.0, icp_bytes)}
         dom = max(kern, key=lambda q: kern[q][0])
         ach = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9 if kern[dom][0] > 0 else 0.0
         roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
                         traffic=None, launch_ms=round(kern[dom][0], 4), algorithmic_bytes_per_launch=kern[dom][1],
-                        numerator="SURVEY 8(d): B_icp = iters*n*72 + 2*14*W*H per frame" if dom == "k_icp_pipeline" else "SURVEY 8(d): N*B_tmpl per frame",
+                        numerator="iters*n*72 (SURVEY 8(d)) + 2*14*w*h of the two template-sized crops per refined frame" if dom == "k_icp_pipeline" else "SURVEY 8(d): N*B_tmpl per frame",
                         note="HIP events on the launch stream; PMC traffic is collected for the default line only (profiles/)")
         if cpu_baseline is not None and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, bank, scenes, K)
@@ -289,6 +321,8 @@ def run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames, cpu_bas
         dist.all_gather_object(ids, int(ctx.device))
         dev_ids = ids
     cap_now = det.grow_candidates(B)                                        # no overflow pending: just reports the capacity
+    if mg is not None:
+        mg.close()
     det.close()
     return {
         "metric": "frames/sec (640x480 RGB-D x N templates, 20 ICP iters)",
@@ -303,7 +337,8 @@ def run(args, ctx, dist, world, rank, w, h, K, build_bank, build_frames, cpu_bas
                    "note": "weak scaling in TEMPLATES: the frames are the same on every rank, the bank grows with the ranks"},
         "collectives": {"backend": (dist.get_backend() if dist is not None else None), "ranks": world, "device_ids": dev_ids,
                         "all_gather_bytes_per_step": world * rec_bytes, "all_reduce_bytes_per_step": B * 17 * 4,
-                        "path": "device (select + refine on the GPU, collectives on a second stream, pipelined one step deep)" if device_path
+                        "path": "C++ host (libfealess_mg.so: ncclAllGather / ncclAllReduce queued on the context's stream from C++, one host wait per step)" if cxx
+                                else "device (select + refine on the GPU, collectives on a second stream, pipelined one step deep)" if device_path
                                 else "host merge (records and poses staged through the host)",
                         "host_syncs_per_step": round(syncs_per_step, 2),
                         "host_merge_comparison": compare},

@@ -102,6 +102,10 @@ extern "C" int fl_context_create(int device, fl_context **out)
   return FL_OK;
 }
 
+extern "C" void *fl_context_get_stream(fl_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int fl_context_get_device(const fl_context *ctx) { return ctx ? ctx->device : -1; }
+extern "C" fl_context *fl_detector_get_context(fl_detector *det) { return det ? det->ctx : nullptr; }
+
 extern "C" int fl_context_set_option(fl_context *ctx, const char *name, long value)
 {
   if (!ctx || !name) return FL_ERR_INVALID;

@@ -103,7 +103,9 @@
 #define FL_ICP_ALLPROD 1          // with the block sums in the 256-thread kernel: the chain wave produces rows too (tiles of 256 rows)
 #endif
 #ifndef FL_ICP_CHAIN_SIMD
-#define FL_ICP_CHAIN_SIMD 1       // 256-thread kernel: elect the chain wave so that the chain waves of a CU's workgroups sit on different SIMDs
+#define FL_ICP_CHAIN_SIMD 0       // 256-thread kernel: elect the chain wave so that the chain waves of a CU's workgroups sit on different SIMDs
+                                  // (chain_elect).  Measured at 4096 frames, one box: 33.49 against 33.50 ms per launch -- SIMD issue
+                                  // slots are not what the launch waits for (profiles/README.md, round 4) -- so wave 0 chains; 1 builds it in
 #endif
 #ifndef FL_ICP_SPEC
 #define FL_ICP_SPEC 1             // parity mode, organised search: the next iteration's search runs while the chain wave adds dist_mean

@@ -1211,7 +1211,17 @@ extern "C" int fl_frame_counters(fl_detector *det, int frame, int32_t out[4])
   if (!det->finalized || frame < 0 || frame >= det->max_batch) return fl_set_error(ctx, FL_ERR_INVALID, "frame");
   FL_HIP(ctx, hipSetDevice(ctx->device));
   FL_HIP(ctx, hipMemcpyAsync(out, det->d_ws + (size_t)frame * det->ws_stride + det->off_count, 16, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t bm[2 * FL_TILE_WORDS];
+  const bool lazy = det->lazy && det->L > 1 && frame < det->last_batch;
+  if (lazy)        // level 0's two tile bitmaps: [0] tiles whose spread bytes are read, [1] tiles whose pixels are quantised
+    FL_HIP(ctx, hipMemcpyAsync(bm, det->d_ws + (size_t)frame * det->ws_stride + det->off_tiles, sizeof(bm), hipMemcpyDeviceToHost, ctx->stream));
   FL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  out[3] = -1;
+  if (lazy) {
+    int n = 0;
+    for (int k = 0; k < FL_TILE_WORDS; ++k) n += __builtin_popcount(bm[FL_TILE_WORDS + k]);
+    out[3] = n;
+  }
   return FL_OK;
 }
 

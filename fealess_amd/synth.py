@@ -113,6 +113,41 @@ def render(w, h, R_obj, t_obj, seed=0, plane_z=1200.0, noise=True, background=Tr
     return depth, bgr, mask
 
 
+def render_clutter(w, h, poses, seed=0, fx=FX, fy=FY, cx=CX, cy=CY):
+    """A cluttered frame: every (R, t) of `poses` is an instance of the object (nearest surface wins per pixel), in front of
+    a NON-planar background (a tilted, rippled wall 1000 - 1350 mm away with box-shaped steps) that carries a high-contrast
+    texture -- colour gradients and depth normals all over the image, unlike render()'s smooth wall.
+    Returns depth (h, w) uint16 mm, bgr (h, w, 3) uint8, masks (one bool image per instance, visible pixels only)."""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    # background surface: tilt + two ripples + blocks of 40 - 90 mm steps
+    bg_z = 1180.0 + 0.22 * (u - cx) - 0.15 * (v - cy) + 45.0 * np.sin(u / 41.0) * np.cos(v / 33.0) + 25.0 * np.sin((u + 2 * v) / 19.0)
+    for _ in range(14):
+        x0, y0 = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+        bw, bh = int(rng.integers(30, 140)), int(rng.integers(30, 120))
+        bg_z[y0:y0 + bh, x0:x0 + bw] -= float(rng.integers(40, 90))
+    # background texture: checker x stripes with random per-cell albedo (edges every 12 - 20 pixels)
+    cell = (np.floor(u / 17.0) + np.floor(v / 13.0)).astype(np.int64)
+    alb = 60.0 + 150.0 * (((cell * 2654435761) >> 7) % 8) / 7.0
+    stripes = 0.75 + 0.25 * np.sign(np.sin((u - v) / 6.0))
+    bg = (alb * stripes)[..., None] * np.array([1.0, 0.9, 0.8])
+    depth = bg_z.copy()
+    col = bg.copy()
+    masks = []
+    zbuf = np.full((h, w), np.inf)
+    for j, (R, t) in enumerate(poses):
+        d_j, c_j, m_j = render(w, h, R, t, seed=seed * 17 + j, noise=False, background=False, fx=fx, fy=fy, cx=cx, cy=cy)
+        zj = np.where(m_j, d_j.astype(np.float64), np.inf)
+        win = zj < zbuf
+        zbuf = np.where(win, zj, zbuf)
+        depth = np.where(win, zj, depth)
+        col = np.where(win[..., None], c_j.astype(np.float64), col)
+        masks = [m & ~win for m in masks] + [win.copy()]
+    depth = depth + rng.integers(-1, 2, size=depth.shape)
+    col = col + rng.normal(0, 1.5, size=col.shape)
+    return (np.clip(np.rint(depth), 0, 65535).astype(np.uint16), np.clip(np.rint(col), 0, 255).astype(np.uint8), masks)
+
+
 def object_pose(tx=0.0, ty=0.0, tz=650.0, yaw=0.3, tilt=0.35, roll=0.1):
     R = rot_z(yaw) @ rot_x(tilt) @ rot_y(roll)
     return R, np.array([tx, ty, tz], np.float64)

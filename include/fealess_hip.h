@@ -133,6 +133,11 @@ const char *fl_last_error(const fl_context *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL restores the context's own */
 int  fl_context_set_stream(fl_context *ctx, void *hip_stream);
 int  fl_context_synchronize(fl_context *ctx);
+/* the stream the context queues its work on (a hipStream_t), its device, and a detector's context: what a host layer
+ * that adds its own stream-ordered work (libfealess_mg.so: the RCCL collectives of the template-sharded path) needs */
+void *fl_context_get_stream(fl_context *ctx);
+int  fl_context_get_device(const fl_context *ctx);
+fl_context *fl_detector_get_context(fl_detector *det);
 /* Development / comparison switches.  They change how the work is scheduled, never a result: "scan_prune" (1; 0 = the scan adds
  * every feature everywhere, as the reference does), "scan_prune_mid" (bit mask of the 8-feature groups after which a modality
  * checks the pruning bound; -1 = built-in), "icp_wide" (-1 = by batch size; 0 / 1 force the 256- / 1024-thread ICP workgroup),
@@ -347,8 +352,9 @@ int  fl_select_best_batch(fl_detector *det, const void *dev_gathered, int n_rank
 int  fl_refine_selected(fl_detector *det, int n_frames, const fl_intrinsics *K, const fl_recognition_params *params,
                         const uint16_t *depth_base, size_t depth_stride, float *dev_rows);
 
-/* diagnostics: per-frame counters of the last match {coarse candidates, matches after sort/unique,
- * overflow flag, 0} (host memory) */
+/* diagnostics: per-frame counters of the last match {coarse candidates, matches after sort/unique, overflow flag,
+ * level-0 tiles (60 x 60 pixels) whose colour quantisation the lazy fine levels computed; -1 when the batch ran eagerly}
+ * (host memory) */
 int  fl_frame_counters(fl_detector *det, int frame, int32_t out[4]);
 
 /* per-stage device time (ms) of the last fl_recognize_* call, by stage index; for bench.py */

@@ -34,6 +34,20 @@ def test_header_symbols_all_exported_and_bound():
     assert lib.fl_abi_version() == 1
 
 
+def test_mg_header_symbols_all_exported_and_bound():
+    """include/fealess_mg.h (the C++ multi-GPU host on RCCL): the library loads without a GPU and exports what it declares."""
+    hdr = open(os.path.join(ROOT, "include", "fealess_mg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fl_mg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 5
+    lib = L.load_mg()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in fealess_mg.h but not exported"
+    assert declared == set(L.MG_SIGNATURES), declared ^ set(L.MG_SIGNATURES)
+    assert C.sizeof(L.MgResult) == 4 + 4 + 20 + 64
+    assert lib.fl_mg_create(None, None, 1, 0, 0, 0, 1, C.byref(C.c_void_p())) == L.FL_ERR_INVALID     # argument checks need no GPU
+
+
 def test_no_cpu_fallback():
     if _has_gpu():
         pytest.skip("a GPU is present")

@@ -177,3 +177,47 @@ def test_c5_64_frames_x_2000_templates_in_batches_of_8_equal_one_batch_and_the_o
             assert g["best"]["template_id"] == e["best"]["template_id"] and g["best"]["x"] == e["best"]["x"] and g["best"]["y"] == e["best"]["y"]
             assert g["best"]["similarity"] == e["best"]["similarity"]
             assert g["det"]["n_points"] == e["det"]["n_points"] and np.array_equal(_bits(g["pose"]), _bits(e["pose"])), i
+
+
+def test_cxx_multi_gpu_host_with_one_rank_equals_fl_recognize_batch(ctx, oracle):
+    """libfealess_mg.so (include/fealess_mg.h): the C++ host of the template-sharded path, RCCL initialised with ONE rank
+    (all-gather of 1, all-reduce of 1: the collectives run, on the context's stream) = fl_recognize_batch on the same bank,
+    bit for bit; also with 64-entry candidate buffers that every frame overflows (grown inside fl_mg_recognize_batch)."""
+    import torch
+    sc = synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=13, n_views=4, n_random=56)
+    frames_b = [sc["bgr"], np.roll(sc["bgr"], 10, axis=1), np.full_like(sc["bgr"], 90), np.roll(sc["bgr"], -16, axis=1)]
+    frames_d = [sc["depth"], np.roll(sc["depth"], 10, axis=1), np.full_like(sc["depth"], 1200), np.roll(sc["depth"], -16, axis=1)]
+    n = len(frames_b)
+    d_b = torch.from_numpy(np.stack(frames_b)).cuda()
+    d_d = torch.from_numpy(np.stack(frames_d).view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    bp = [d_b.data_ptr() + i * 640 * 480 * 3 for i in range(n)]
+    dp = [d_d.data_ptr() + i * 640 * 480 * 2 for i in range(n)]
+    ref_det = api.Detector(ctx, 2, T2)
+    ref_det.add_class(sc["bank"])
+    ref_det.finalize(640, 480, max_batch=n)
+    for thr, cap in ((75.0, 0), (-100.0, 64)):
+        params = L.RecognitionParams(thr, 10, 0.5, 0.01, L.FL_ICP_PARITY)
+        ref = ref_det.recognize_batch(frames_b, frames_d, sc["K"], thr, 10, 0.5, 0.01)
+        det = api.Detector(ctx, 2, T2)
+        det.add_class(sc["bank"])
+        det.finalize(640, 480, max_batch=n, max_candidates=cap)
+        mg = api.MgGroup(det, api.MgGroup.unique_id(), 1, 0, 0, sc["bank"].n_pyramids, 16)
+        got = mg.recognize_batch(bp, dp, sc["K"], params)
+        st = mg.stats()
+        assert st["allgather_bytes"] == n * 16 * 20 and st["allreduce_bytes"] == n * 17 * 4
+        assert (st["attempts"] > 1) == (cap == 64)
+        for f in range(n):
+            e, g = ref[f], got[f]
+            assert g.status == 0 and g.found == e["found"], (thr, f)
+            if e["n_matches"] > 0:
+                assert (g.best.x, g.best.y, g.best.template_id, g.best.class_idx) == (e["best"]["x"], e["best"]["y"], e["best"]["template_id"], e["best"]["class_idx"])
+                assert np.float32(g.best.similarity) == e["best"]["similarity"]
+            else:
+                assert g.best.template_id == -1
+            if e["found"]:
+                assert np.array_equal(_bits(np.array(g.pose, np.float32)), _bits(e["pose"].reshape(-1))), (thr, f)
+        mg.close()
+        det.close()
+    assert ref[0]["found"] == 1 and ref[2]["found"] == 0
+    ref_det.close()

@@ -229,3 +229,14 @@ def test_template_sharded_single_rank_line_has_roofline_and_cpu_baseline():
     assert out["roofline"] is not None and out["roofline"]["launch_ms"] > 0 and out["cpu_baseline"]["value"] > 0
     assert out["collectives"]["host_syncs_per_step"] <= 1.5
     assert out["collectives"]["host_merge_comparison"]["same_result"] is True
+
+
+def test_template_sharded_cxx_host_single_rank_line():
+    """`bench.py --shard templates --mg-host cxx`: the step driven by the C++ host (libfealess_mg.so: ncclCommInitRank,
+    ncclAllGather, ncclAllReduce from C++), one rank on the one GPU; every frame equals the single detector's result."""
+    out = _run_bench(["--shard", "templates", "--mg-host", "cxx", "--templates", "40", "--batch", "8", "--scenes", "3", "--steps", "3",
+                      "--warmup", "1", "--icp-iters", "8", "--topk", "16", "--no-cpu-baseline", "--verify-sharded", "--compare-host-merge"])
+    assert out["n_gpus"] == 1 and out["verified_against_single_detector"] is True, out
+    assert out["collectives"]["path"].startswith("C++ host")
+    assert out["collectives"]["host_syncs_per_step"] <= 1.01
+    assert out["collectives"]["host_merge_comparison"]["same_result"] is True
