@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 L2_PEAK_GBS = 34500.0        # same guide: aggregate L2 bandwidth over the 8 XCDs
 FORCE_ALL_ITERS = -3.0e38    # dist_diff_thr that never stops the loop: exactly icp_it_thr iterations
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def parse():
@@ -146,6 +146,48 @@ def build_bank(ctx, args, n_templates, w, h, K, spread_trained=False):
         else:                                     # no depth render: they never win against the trained views
             bank.add_pyramid(synth.random_pyramid(rng, levels, 2, w, h), None, None)
     return bank, scenes
+
+
+def build_clutter(ctx, args, n_templates, w, h, K, n_scenes=6):
+    """The cluttered workload: every scene holds THREE instances of the object in front of a textured, non-planar background
+    (synth.render_clutter: colour labels on about half of the pixels instead of 1 - 2 %, depth labels that change all over the
+    image), and the bank holds four near-by rendered views per instance (1 - 2 degrees / a few mm apart: several of them pass
+    threshold 75 on the same instance, so the scan's candidates, the marked tiles and the refinement all grow), padded with
+    random templates.  What the reference's per-template loop costs regardless of content (linemod.cpp:1471-1506) and what
+    its refinement costs per candidate (:1509-1573)."""
+    from fealess_amd import synth
+    from fealess_amd.bank import TemplateBank
+    levels = args.levels
+    fx, fy, cx, cy = K
+    rng = np.random.default_rng(4321)
+    scenes, trained = [], []
+    slots = [(-170.0, -50.0), (10.0, 60.0), (175.0, -35.0)]
+    for s in range(n_scenes):
+        poses = []
+        for (sx, sy) in slots:
+            R, t = synth.object_pose(tx=sx + float(rng.uniform(-25, 25)), ty=sy + float(rng.uniform(-25, 25)), tz=float(rng.uniform(620, 720)),
+                                     yaw=float(rng.uniform(-0.6, 0.6)), tilt=float(rng.uniform(0.2, 0.5)), roll=float(rng.uniform(-0.15, 0.25)))
+            poses.append((R, t))
+        depth, bgr, _ = synth.render_clutter(w, h, poses, seed=500 + s, fx=fx, fy=fy, cx=cx, cy=cy)
+        scenes.append((bgr, depth))
+        for j, (R, t) in enumerate(poses):
+            for v in range(4):
+                dR = synth.rot_z(np.deg2rad(rng.uniform(-1.5, 1.5))) @ synth.rot_x(np.deg2rad(rng.uniform(-1.5, 1.5)))
+                tt = t + np.array([rng.uniform(-8, 8), rng.uniform(-8, 8), rng.uniform(-5, 5)])
+                seed = 5000 + 100 * s + 10 * j + v
+                d_bg, bgr_v, mask = synth.render(w, h, dR @ R, tt, seed=seed, noise=False, background=True, fx=fx, fy=fy, cx=cx, cy=cy)
+                ex = ctx.extract_template_pyramid(bgr_v, d_bg, (mask * 255).astype(np.uint8), levels)
+                if ex is None or len(trained) >= n_templates:
+                    continue
+                d_obj, _, _ = synth.render(w, h, dR @ R, tt, seed=seed, noise=False, background=False, fx=fx, fy=fy, cx=cx, cy=cy)
+                trained.append((ex[0], synth.pose13(dR @ R, tt), (d_obj.astype(np.uint32) * 10).clip(0, 65535).astype(np.uint16)))
+    bank = TemplateBank("obj", levels, 2)
+    for i in range(n_templates):
+        if i < len(trained):
+            bank.add_pyramid(*trained[i])
+        else:
+            bank.add_pyramid(synth.random_pyramid(rng, levels, 2, w, h), None, None)
+    return bank, scenes, len(trained)
 
 
 def build_frames(scenes, B, rank, w, h, same_on_all_ranks=False):
@@ -264,7 +306,7 @@ def source_digest():
 class Runner:
     """One finalized detector + resident device frames of one workload."""
 
-    def __init__(self, ctx, args, bank, bgrs, depths, w, h, K, eager=False, max_candidates=4096):
+    def __init__(self, ctx, args, bank, bgrs, depths, w, h, K, eager=False, max_candidates=4096, device_frames=None, max_batch=None):
         import torch
         from fealess_amd import api
         from fealess_amd import _lib as L
@@ -273,11 +315,14 @@ class Runner:
         self.det = api.Detector(ctx, 2, t_pyramid(args.levels))
         self.det.add_class(bank)
         ctx.set_option("eager_frontend", 1 if eager else 0)      # sampled by fl_detector_finalize
-        self.B = len(bgrs)
+        self.B = max_batch if max_batch is not None else len(bgrs)
         self.det.finalize(w, h, max_batch=self.B, max_candidates=max_candidates)
         ctx.set_option("eager_frontend", 0)
-        self.d_bgr = torch.from_numpy(bgrs).cuda()
-        self.d_depth = torch.from_numpy(depths.view(np.int16)).cuda()
+        if device_frames is not None:                          # frames another Runner already uploaded
+            self.d_bgr, self.d_depth = device_frames
+        else:
+            self.d_bgr = torch.from_numpy(bgrs).cuda()
+            self.d_depth = torch.from_numpy(depths.view(np.int16)).cuda()
         torch.cuda.synchronize()
         self.bptr = [self.d_bgr.data_ptr() + i * w * h * 3 for i in range(self.B)]
         self.dptr = [self.d_depth.data_ptr() + i * w * h * 2 for i in range(self.B)]
@@ -677,6 +722,43 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
                           icp_ms=round(t["icp_ms"], 4), device_ms_last_step=round(t["total_ms"], 4)))
     out["batch_sweep"] = sweep
     out["batch1_latency_ms"] = sweep[0]["ms_per_step"] if sweep and sweep[0]["batch"] == 1 else None
+    # Small batches leave most of the chip idle (the ICP launch of b <= 256 frames occupies b CUs), and the reference's
+    # caller hands over one camera frame at a time (test/linemod_recon.cpp:44-111).  Several cameras / streams overlap on one
+    # GPU with the entry points that exist for it: K contexts (one HIP stream each) with a detector each, batches submitted
+    # round-robin (fl_recognize_submit) and collected K submissions later (fl_recognize_collect).  Same results (same kernels
+    # on the same frames); the latency of one batch stays what batch_sweep says.
+    from fealess_amd import api as _api
+    piped = []
+    for b, kpipes in ((1, 8), (8, 8), (64, 4), (256, 2)):
+        if b > args.batch:
+            continue
+        ctxs = [_api.Context(ctx.device) for _ in range(kpipes)]
+        runs = [Runner(c, args, bank, None, None, w, h, K, device_frames=(run.d_bgr, run.d_depth), max_batch=b) for c in ctxs]
+        for r_ in runs:                                        # warm-up
+            r_.step(b)
+        for r_ in runs:
+            r_.collect(b)
+        base = next(e for e in sweep if e["batch"] == b)
+        steps = int(max(4 * kpipes, min(400, 0.5 / max(base["ms_per_step"] * 1e-3 / kpipes, 1e-5))))
+        t0 = time.perf_counter()
+        for i in range(steps):
+            r_ = runs[i % kpipes]
+            if i >= kpipes:
+                r_.collect(b)                                  # the batch this pipeline queued kpipes submissions ago
+            r_.step(b)
+        last = [r_.collect(b)[0] for r_ in runs]
+        el = time.perf_counter() - t0
+        found = sum(int(x.found) for x in last[0])
+        piped.append(dict(batch=b, pipelines=kpipes, frames_per_s=round(b * steps / el, 1), ms_per_batch_amortised=round(el / steps * 1e3, 4),
+                          speedup_vs_one_pipeline=round((b * steps / el) / base["frames_per_s"], 2), detections_last_batch=f"{found}/{b}"))
+        for r_ in runs:
+            r_.det.close()
+            r_.det = None
+        for c in ctxs:
+            c.close()
+    out["batch_sweep_pipelined"] = piped
+    out["batch_sweep_pipelined_note"] = ("K contexts x (detector, HIP stream), batches submitted round-robin and collected K submissions later: "
+                                         "throughput of several camera streams on one GPU at small batches; per-batch latency is batch_sweep's")
     out["batch_sweep_note"] = ("one Recognition() per camera frame is the reference's call pattern; batches that leave CUs idle run one "
                                "1024-thread ICP workgroup per frame, full batches 256-thread ones (4 or 5 per CU, whichever finishes the batch sooner)")
     if bank.n_pyramids > 360:
@@ -707,6 +789,22 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
                                 scan_ms=round(t["scan_ms"], 4),
                                 note="option scan_prune = 0: every template's every feature added at every position (the reference's work); "
                                      "same results")
+    if not args.eager_frontend:
+        # both data-dependent savings off in ONE run: whole-image fine levels AND every addition of the scan -- the figure that
+        # does not depend on what the frames show
+        r5 = Runner(ctx, args, bank, None, None, w, h, K, eager=True, device_frames=(run.d_bgr, run.d_depth), max_batch=args.batch)
+        ctx.set_option("scan_prune", 0)
+        try:
+            el = r5.timed(4, 1)
+            _, t = r5.collect()
+        finally:
+            ctx.set_option("scan_prune", 1)
+        out["eager_unpruned"] = dict(value=round(args.batch * 4 / el, 1), unit="frames/s", ms_per_step=round(el / 4 * 1e3, 4),
+                                     stage_ms={k: round(v, 4) for k, v in t.items() if k.endswith("_ms")},
+                                     note="eager front-end AND unpruned scan together: the DATA-INDEPENDENT figure of the whole step (the "
+                                          "reference's work on every frame, whatever it shows); same results")
+        r5.det.close()
+        r5.det = None
     if args.icp_mode == "parity":
         # FL_ICP_FAST (parallel sums instead of the reference's float32 chains): within 1e-4 of the EXACT sums, not of the reference's
         # float32 result (tests/test_gpu_icp.py::test_icp_fast_mode_close_to_fp64_yardstick, ::test_icp_fast_mode_recognition_vs_the_f32_oracle)
@@ -726,9 +824,77 @@ def extras(args, ctx, run, bank, bgrs, depths, w, h, K):
                                     "sums); NOT the mode that meets the 1e-4 bar against the reference -- FL_ICP_PARITY does, with 0; never "
                                     "the headline value")
         r4.close()
-    run.close()                                           # the default workload's 16 GB of workspaces make room for the other configs
+    # configs[4]'s per-GPU shape on this GPU: 64 frames x 2000 templates as eight batches of 8 (what each of 8 GPUs would run)
+    if args.batch >= 64:
+        el8 = run.timed(8 * 4, 8, n=8)
+        _, t8 = run.collect(8)
+        p8 = next((e for e in out.get("batch_sweep_pipelined", []) if e["batch"] == 8), None)
+        out["c5_64x2000_batch8"] = dict(frames_per_s=round(8 * 32 / el8, 1), ms_per_64_frames=round(el8 / 4 * 1e3, 4), ms_per_batch_of_8=round(el8 / 32 * 1e3, 4),
+                                        icp_ms_per_batch=round(t8["icp_ms"], 4), pipelined_frames_per_s=(p8["frames_per_s"] if p8 else None),
+                                        workload=f"BASELINE configs[4] per-GPU shape: 8 frames x {bank.n_pyramids} templates per call, eight calls "
+                                                 "back to back = the node's 64-frame batch on one GPU; pipelined_frames_per_s = the same "
+                                                 "calls over 8 contexts (batch_sweep_pipelined); parity of this shape: "
+                                                 "tests/test_gpu_configs.py::test_c5_64_frames_x_2000_templates_in_batches_of_8_equal_one_batch_and_the_oracle")
+    run.close()                                           # the default workload's 26 GB of workspaces make room for the other configs
+    out.update(clutter_config(args, ctx, w, h, K))
+    out.update(c4_config(args, ctx, w, h, K))
     out.update(other_configs(args, ctx))
     return out
+
+
+def clutter_config(args, ctx, w, h, K):
+    """The cluttered workload beside the headline (same shape: 640x480, 2000 templates, 2 levels, 20 forced ICP iterations)."""
+    a = argparse.Namespace(**vars(args))
+    a.batch = min(args.batch, 2048)
+    bank, scenes, n_trained = build_clutter(ctx, a, a.templates, w, h, K)
+    bgrs, depths = build_frames(scenes, a.batch, 0, w, h)
+    r = Runner(ctx, a, bank, bgrs, depths, w, h, K, max_candidates=65536)
+    el = r.timed(4, 1)
+    res, t = r.collect()
+    cnt = np.array([r.det.frame_counters(i) for i in range(0, a.batch, max(1, a.batch // 64))], np.float64)
+    tiles_total = ((w + 59) // 60) * ((h + 59) // 60)
+    out = dict(value=round(a.batch * 4 / el, 1), unit="frames/s", ms_per_step=round(el / 4 * 1e3, 4), frames_per_step=a.batch,
+               stage_ms={k: round(v, 4) for k, v in t.items() if k.endswith("_ms")},
+               detections=f"{sum(int(x.found) for x in res)}/{a.batch}", overflowed_frames=int(sum(int(x.status) != 0 for x in res)),
+               coarse_candidates_per_frame=round(float(cnt[:, 0].mean()), 1), matches_per_frame=round(float(cnt[:, 1].mean()), 1),
+               marked_level0_tile_fraction=round(float(cnt[:, 3].mean()) / tiles_total, 3),
+               icp_points_mean=round(float(np.mean([int(x.det.n_points) for x in res if x.found] or [0])), 1),
+               trained_views=n_trained,
+               workload=f"clutter: 640x480, {bank.n_pyramids} templates ({n_trained} rendered views: 4 near-by views of each of 3 object instances "
+                        f"in {len(scenes)} scenes, the rest random), textured non-planar background, 3 objects per frame, {a.icp_iters} ICP "
+                        "iterations forced on the best match (fealess_amd/synth.py::render_clutter, bench.py::build_clutter)")
+    r.ctx.set_option("scan_prune", 0)
+    try:
+        el2 = r.timed(3, 1)
+        _, t2 = r.collect()
+    finally:
+        r.ctx.set_option("scan_prune", 1)
+    out["scan_unpruned_ms"] = round(t2["scan_ms"], 4)
+    out["ms_per_step_scan_unpruned"] = round(el2 / 3 * 1e3, 4)
+    r.close()
+    return {"clutter": out}
+
+
+def c4_config(args, ctx, w, h, K):
+    """BASELINE configs[3]'s bank on ONE GPU: a single detector over 16000 templates (what the eight 2000-template ranks must add
+    up to; the sharded path itself is `--shard templates`, its parity tests/test_gpu_configs.py)."""
+    a = argparse.Namespace(**vars(args))
+    a.templates, a.batch = 16000, min(args.batch, 1024)
+    bank, scenes = build_bank(ctx, a, a.templates, w, h, K, spread_trained=True)
+    bgrs, depths = build_frames(scenes, a.batch, 0, w, h)
+    r = Runner(ctx, a, bank, bgrs, depths, w, h, K)
+    el = r.timed(3, 1)
+    res, t = r.collect()
+    full = unpruned_scan_ms(r, steps=2)
+    out = dict(value=round(a.batch * 3 / el, 1), unit="frames/s", ms_per_step=round(el / 3 * 1e3, 4), frames_per_step=a.batch,
+               stage_ms={k: round(v, 4) for k, v in t.items() if k.endswith("_ms")}, scan_ms=round(t["scan_ms"], 4), unpruned_scan_ms=round(full, 4),
+               scan_l2_frac=round(gbs(t["scan_algorithmic_bytes"], full) / L2_PEAK_GBS, 4),
+               detections=f"{sum(int(x.found) for x in res)}/{a.batch}",
+               winner_template_ids=sorted({int(x.best.template_id) for x in res if x.found})[:12],
+               workload=f"BASELINE configs[3]'s bank on one GPU: 640x480, {bank.n_pyramids} templates in ONE detector (trained views dealt evenly over the "
+                        f"bank, global ids up to {bank.n_pyramids - 1}), 2 levels, {a.icp_iters} ICP iterations forced")
+    r.close()
+    return {"c4_16000_templates_1gpu": out}
 
 
 def other_configs(args, ctx):

@@ -99,6 +99,9 @@
                                   // per CU nobody waits for the chain, and a phase B that runs as fast as memory lets it only takes the
                                   // memory side from the co-resident workgroups' phases); 0: always term by term
 #endif
+#ifndef FL_ICP_BPD
+#define FL_ICP_BPD 1              // dist_mean phase: tiles of (mod, ref, bnd) loads a producer thread keeps in flight (1 or 2)
+#endif
 #ifndef FL_ICP_ALLPROD
 #define FL_ICP_ALLPROD 1          // with the block sums in the 256-thread kernel: the chain wave produces rows too (tiles of 256 rows)
 #endif
@@ -1063,22 +1066,50 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
     else if (clane == 0) acc = chain_tile<SH::CHAIN_NBUF>(col, rows, acc);
   };
   const bool chain_wave = __builtin_amdgcn_readfirstlane(clane) >= 0;
-  if (allprod) {
-    // every wave produces; the chain wave adds tile t - 1 (complete since the last barrier, the other buffer) behind its own rows of tile t
+  // producer loop: `before_barrier(t)` runs behind the rows of tile t (the chain wave's block sum of tile t - 1 when every wave
+  // produces).  FL_ICP_BPD tiles of loads in flight per thread: register sets that trade roles by unrolling (see above).
+  auto produce = [&](auto &&before_barrier) {
+#if FL_ICP_BPD >= 2
+    Row X, Y, Z;
+    if (ntiles > 0) { row_load(X, 0); row_load(Y, 1); }
+    for (int t = 0; t < ntiles; t += 3) {
+      row_load(Z, t + 2);
+      row_process(X, t);
+      before_barrier(t);
+      PR_STAMP_BARRIER(28, 3);
+      if (t + 1 < ntiles) {
+        row_load(X, t + 3);
+        row_process(Y, t + 1);
+        before_barrier(t + 1);
+        tile_barrier();
+      }
+      if (t + 2 < ntiles) {
+        row_load(Y, t + 4);
+        row_process(Z, t + 2);
+        before_barrier(t + 2);
+        tile_barrier();
+      }
+    }
+#else
     Row A, B;
     if (ntiles > 0) row_load(A, 0);
     for (int t = 0; t < ntiles; t += 2) {
       row_load(B, t + 1);
       row_process(A, t);
-      if (chain_wave && t > 0) chain_step(t - 1);
+      before_barrier(t);
       PR_STAMP_BARRIER(28, 2);
       if (t + 1 < ntiles) {
         row_load(A, t + 2);
         row_process(B, t + 1);
-        if (chain_wave) chain_step(t);
+        before_barrier(t + 1);
         tile_barrier();
       }
     }
+#endif
+  };
+  if (allprod) {
+    // every wave produces; the chain wave adds tile t - 1 (complete since the last barrier, the other buffer) behind its own rows of tile t
+    produce([&](int t) { if (chain_wave && t > 0) chain_step(t - 1); });
   } else if (chain_wave) {
     // the chain wave's own loop (see the A2 phase): one barrier per tile like the producers' below
     CH_STAMP_BEGIN;
@@ -1090,18 +1121,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
     }
     CH_STAMP_END(26);
   } else if (slot >= 0) {
-    Row A, B;
-    if (ntiles > 0) row_load(A, 0);
-    for (int t = 0; t < ntiles; t += 2) {
-      row_load(B, t + 1);
-      row_process(A, t);
-      PR_STAMP_BARRIER(28, 2);
-      if (t + 1 < ntiles) {
-        row_load(A, t + 2);
-        row_process(B, t + 1);
-        tile_barrier();
-      }
-    }
+    produce([&](int) {});
   } else {
     for (int t = 0; t < ntiles; ++t) tile_barrier();       // a wave that neither chains nor produces (1024-thread workgroup)
   }

@@ -217,7 +217,25 @@ def test_cxx_multi_gpu_host_with_one_rank_equals_fl_recognize_batch(ctx, oracle)
                 assert g.best.template_id == -1
             if e["found"]:
                 assert np.array_equal(_bits(np.array(g.pose, np.float32)), _bits(e["pose"].reshape(-1))), (thr, f)
+        if cap == 0:
+            assert ref[0]["found"] == 1 and ref[2]["found"] == 0     # (at threshold 75: the blank frame matches nothing)
         mg.close()
         det.close()
-    assert ref[0]["found"] == 1 and ref[2]["found"] == 0
     ref_det.close()
+
+
+def test_context_options_are_explicit_state_not_the_environment(ctx, monkeypatch):
+    """fl_context_set_option / _get_option: the development switches are context state.  Their initial values come from the
+    environment ONCE, at fl_context_create; a variable that appears in the process environment afterwards changes nothing
+    (round 3 read FL_SCAN_PRUNE & co. with getenv on every launch)."""
+    assert ctx.get_option("scan_prune") == 1 and ctx.get_option("icp_wide") == -1 and ctx.get_option("icp_order") == 1
+    monkeypatch.setenv("FL_SCAN_PRUNE", "0")                 # a stray variable in a host's environment, after the context exists
+    monkeypatch.setenv("FL_ICP_WIDE", "1")
+    assert ctx.get_option("scan_prune") == 1 and ctx.get_option("icp_wide") == -1
+    c2 = api.Context(0)                                       # a context created NOW takes them as its initial values
+    assert c2.get_option("scan_prune") == 0 and c2.get_option("icp_wide") == 1
+    c2.set_option("scan_prune", 1)
+    assert c2.get_option("scan_prune") == 1
+    with pytest.raises(api.FealessError):
+        c2.set_option("no_such_switch", 1)
+    c2.close()

@@ -36,7 +36,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   timeout -k 10 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_final_$i -- python3 bench.py --steps 2 --warmup 1 --batch $B --templates $T --no-cpu-baseline --no-extras > gpurun_out/pmc_final_$i.log 2>&1 || { echo "pmc group $i failed"; tail -5 gpurun_out/pmc_final_$i.log; exit 1; }
 done
 python3 -c "import bench; print(bench.source_digest())" > gpurun_out/pmc_src_digest.txt
-python3 tools/profile_summarise.py ${TAG:-r03} $B $T --pmc-only || exit 1
+python3 tools/profile_summarise.py ${TAG:-r04} $B $T --pmc-only || exit 1
 }
 for part in ${MODE:-stats bench pmc}; do do_$part || exit 1; done
 if [ -f gpurun_out/bench_final.json ]; then tail -c 600 gpurun_out/bench_final.json; fi

@@ -32,6 +32,9 @@ if not pmc_only:
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
+# the same per kernel restricted to its LARGEST launches (grid size): a kernel that also runs on small inputs (bank building,
+# pyramid levels) has its per-launch averages diluted; "<kernel> @ grid N" is the launch the step time is made of
+rows_by_kernel = collections.defaultdict(list)
 newest = {}
 for f in glob.glob(os.path.join(src, "pmc_final_*", "**", "*counter_collection.csv"), recursive=True):
     grp = os.path.relpath(f, src).split(os.sep)[0]
@@ -42,7 +45,22 @@ for f in newest.values():
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+        rows_by_kernel[k].append((int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 kernels = {k: {c: acc[k][c] / max(1, len(disp[k][c])) for c in sorted(acc[k])} for k in sorted(acc) if k.startswith("k_") or "k_" in k}
+for k, rows in rows_by_kernel.items():
+    if not (k.startswith("k_") or "k_" in k):
+        continue
+    gmax = max(g for g, _, _, _ in rows)
+    if gmax == min(g for g, _, _, _ in rows):
+        continue
+    sel = collections.defaultdict(list)
+    dur = []
+    for g, c, v, ns in rows:
+        if g == gmax:
+            sel[c].append(v)
+            dur.append(ns)
+    kernels[f"{k} @ grid {gmax}"] = dict({c: sum(v) / len(v) for c, v in sorted(sel.items())}, launches=len(dur) // max(1, len(sel)),
+                                         duration_ns_under_pmc=sum(dur) / max(1, len(dur)))
 json.dump({
     "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --batch %d --templates %d "
                "--no-cpu-baseline --no-extras" % (batch, templates),
