@@ -18,9 +18,6 @@
 #include "fl_internal.h"
 #include <float.h>
 
-#ifndef FL_DQ_FAST_NORM
-#define FL_DQ_FAST_NORM 1          // LUT indices from a v_rsq_f32 estimate, the reference's sqrtf + division only near a bin edge (exact either way)
-#endif
 #ifndef FL_CQ_DOT4
 #define FL_CQ_DOT4 1               // horizontal blur taps by v_dot4_u32_u8 against constant weight words
 #endif
@@ -480,30 +477,19 @@ __device__ __forceinline__ unsigned dq_normal_pattern(const uint16_t *__restrict
     ny = (float)(617LL * ddy);
     nz = (float)(-(long long)det * d);
   }
-  const float ss = nx * nx + ny * ny + nz * nz;
-  if (!(ss > 0)) return dq_pattern(0);                      // shadows of the depth sensor (sqrtf(ss) > 0  <=>  ss > 0)
-  // The reference normalises with a correctly rounded sqrtf and a correctly rounded division (:655-661) -- about 30 of this
-  // function's vector instructions -- only to truncate n * 10 + 10 (n_z * 20 + 20) to a LUT index.  The index is a floor, so
-  // an ESTIMATE of the same real number gives the same index unless it lies closer to an integer than the two computations
-  // can differ: the reference's chain is within 4.3e-6 of the real value (5.5 roundings of 2^-24 on a magnitude <= 10, plus
-  // half an ulp of 20), the estimate through v_rsq_f32 (1 ulp) within the same, so they differ by less than 1e-5; lanes whose
-  // estimate lies within 4e-5 (8e-5 for n_z: its scale is 20) of an integer take the reference's own instructions instead --
-  // about one wavefront row in 70.  Exact by construction: tests/test_gpu_frontend.py compares every pixel with the oracle.
-  const float rs = __builtin_amdgcn_rsqf(ss);
-  const float t1 = (nx * rs) * 10 + 10, t2 = (ny * rs) * 10 + 10, t3 = (nz * rs) * 20 + 20;
-  int v1 = (int)t1, v2 = (int)t2, v3 = (int)t3;
-  const float fr1 = __builtin_amdgcn_fractf(t1), fr2 = __builtin_amdgcn_fractf(t2), fr3 = __builtin_amdgcn_fractf(t3);
-  // (bitwise |: one compare chain, no short-circuit branches; a negative or NaN estimate has a fraction near 0 / 1 or fails
-  // every comparison, i.e. takes the exact path as well)
-  const bool near_edge = (int)(__builtin_fabsf(fr1 - 0.5f) > 0.5f - 4e-5f) | (int)(__builtin_fabsf(fr2 - 0.5f) > 0.5f - 4e-5f) |
-                         (int)(__builtin_fabsf(fr3 - 0.5f) > 0.5f - 8e-5f) | (int)!(fminf(fminf(t1, t2), t3) > -1.0f);
-  if (FL_DQ_FAST_NORM == 0 || near_edge) {
-    const float s = sqrtf(ss);
-    const float inv = 1.0f / s;
-    v1 = (int)((nx * inv) * 10 + 10);
-    v2 = (int)((ny * inv) * 10 + 10);
-    v3 = (int)((nz * inv) * 20 + 20);
-  }
+  const float s = sqrtf(nx * nx + ny * ny + nz * nz);
+  if (!(s > 0)) return dq_pattern(0);                       // shadows of the depth sensor
+  // (Round 4 measured the LUT indices from a v_rsq_f32 ESTIMATE with the correctly rounded sqrtf + division only for lanes
+  // within 4e-5 of a bin edge -- exact by construction, bit-equal in the tests -- and it was 2 % SLOWER (front-end 18.04
+  // against 17.70 ms per 4096 eager frames): the test for "near an edge" costs what the two correctly rounded operations
+  // cost, and a wavefront takes the exact branch whenever one of its 64 lanes is near an edge.  profiles/README.md.)
+  const float inv = 1.0f / s;
+  nx *= inv;
+  ny *= inv;
+  nz *= inv;
+  const int v1 = (int)(nx * 10 + 10);
+  const int v2 = (int)(ny * 10 + 10);
+  const int v3 = (int)(nz * 20 + 20);
   // Q7: v3 == 20 is an out-of-bounds read in the reference; defined as 0 here
   if (!(v1 >= 0 && v1 <= 19 && v2 >= 0 && v2 <= 19 && v3 >= 0 && v3 <= 19)) return dq_pattern(0);
   const unsigned v = lut[v2 * 20 + v1];
