@@ -260,7 +260,7 @@ int fl_launch_quantized_orientations_mag(fl_context *ctx, const uint8_t *bgr, si
 
 // ------------------------------------------------------------------------------------------
 // cv::pyrDown.  The stage is bound by vector-memory instructions, whose cost on gfx950 depends on alignment and lane
-// stride much more than on width (tools/dev/ldwidth.hip: a 16-byte load costs ~30 cycles per wave when 4-byte
+// stride much more than on width (tools/probes/ldwidth.hip: a 16-byte load costs ~30 cycles per wave when 4-byte
 // aligned, ~70 at byte alignment or a 6-byte lane stride; a byte load at stride 5 ~25).  So:
 //   k_pyrdown_pairs   interior: one thread makes TWO adjacent output pixels; their 7 source pixels are 21 bytes
 //                     inside the 4-byte aligned 24-byte window starting at 12 x' - 8 -> one 16-byte + one 8-byte

@@ -33,7 +33,7 @@
 // CSR headers and their gathers are not needed there: the reference cloud is kept as an IMAGE (crop pixel -> 12-byte point,
 // a point at infinity where the pixel was dropped; a point is named by its pixel), and the reference points within distance r of a query
 // q can only come from the pixels its ball projects to -- u in [fx (qx -+ r) / (qz +- r)], likewise v -- a window of a
-// few pixels.  Queries are taken in 8x8-pixel tile order (a permutation built once per frame), so the 64 queries of a
+// few pixels.  Queries are taken in 16x4-pixel tile order (a permutation built once per frame), so the 64 queries of a
 // wave share a compact union window; the wave stages that window into its share of the (idle) chain tiles in LDS with a
 // handful of coalesced loads and every lane enumerates its own window from LDS.  When the union does not fit (the first
 // iterations, where sqrt(3 dist_mean) is several pixels) the same enumeration reads the image from L2 instead.
@@ -48,7 +48,10 @@
 #include <set>
 #include <utility>
 
-#define ICP_BS_SMALL 256
+#ifndef FL_ICP_BS_SMALL
+#define FL_ICP_BS_SMALL 256
+#endif
+#define ICP_BS_SMALL FL_ICP_BS_SMALL
 #define ICP_BS_WIDE 1024
 #define ICP_DT 512                 // terms per block of the deferred dist_mean chain (two float4 per lane of the chain wave)
 #ifdef FL_ICP_PHASES
@@ -99,6 +102,12 @@
                                   // per CU nobody waits for the chain, and a phase B that runs as fast as memory lets it only takes the
                                   // memory side from the co-resident workgroups' phases); 0: always term by term
 #endif
+#ifndef FL_ICP_TILE_W
+#define FL_ICP_TILE_W 16          // organised search: the queries of a step come from FL_ICP_TILE_W x (64 / FL_ICP_TILE_W)-pixel tiles.  Wider tiles =
+                                  // longer contiguous runs in the tile-ordered gathers / scatters (mod, bnd, nn: 192 instead of 96 bytes per row piece)
+                                  // against a larger staged rectangle; measured at 4096 frames, ICP ms per launch: 4 x 16 35.4, 8 x 8 33.9 / 33.8,
+                                  // 16 x 4 33.6 / 33.6, 32 x 2 35.8
+#endif
 #ifndef FL_ICP_BPD
 #define FL_ICP_BPD 1              // dist_mean phase: tiles of (mod, ref, bnd) loads a producer thread keeps in flight (1 or 2)
 #endif
@@ -132,7 +141,7 @@
 //   nd     n x f32    organised search, parity mode: squared distance to nn[i] (the search runs ahead of the threshold it is
 //                     compared with, see "Search ahead of the distance chain")
 //   dterm  n x f32    parity mode: the terms of getL2distClouds' dist_mean chain, index order (0 for a dropped pair)
-//   perm   n x i32    organised search: model indices in 8x8-pixel tile order
+//   perm   n x i32    organised search: model indices in 16x4-pixel tile order
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid (grid search)
 //   nrm   n x 3 f32   unit normals of the reference cloud, index order (FL_ICP_POINT_TO_PLANE only; 0 = unknown)
 struct IcpWsLayout {
@@ -256,6 +265,10 @@ struct IcpSharedT {
   static constexpr bool ALLPROD = BSUM && FL_ICP_ALLPROD && NW < 8;
   static constexpr int DTQ = ALLPROD ? BS_ : TQ;
   alignas(16) float dtile[2][DTQ];
+  // the organised search stages ICP_STAGE_CAP points per wave in the tile region above: a workgroup with few waves has small
+  // tiles (TQ rows), so the region is padded up to what its waves stage
+  static constexpr int STAGE_FLOATS = NW * 384 * 4, TILE_FLOATS = 2 * 15 * TS + 2 * DTQ;
+  alignas(16) float stage_pad[STAGE_FLOATS > TILE_FLOATS ? STAGE_FLOATS - TILE_FLOATS : 4];
   alignas(16) float dchain[2][ICP_DT];   // the deferred dist_mean chain's staging (chain wave only)
 #ifdef FL_ICP_PHASES
   long long tacc[16], tlast, tkernel;   // tkernel: clock at kernel entry (k_icp_pipeline)
@@ -1240,7 +1253,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   float old_mean = 0.0f;                                 // dist_mean before the pending distances (pending == 2)
 
   // ---- organised search: PointsCorresponding (:193-279) for every model point, exact 1-NN within min(bnd[i], r_lim) ----
-  // 64 queries of one (or two adjacent) 8x8-pixel tiles per wave and step: window, staging, scan.  Steps are claimed from a
+  // 64 queries of one (or two adjacent) 16x4-pixel tiles per wave and step: window, staging, scan.  Steps are claimed from a
   // workgroup counter (S.a1_next, reset by the caller) where a wave joins late (SPEC), four steps ahead of the one being
   // scanned, so that the loads of the next steps (perm -> mod, bnd) are in flight; otherwise wave w takes steps w, w + NW, ...
   // found(active, i, qx, qy, qz, j, d): j = -1, d = NaN when no reference point lies within the radius.
@@ -1255,7 +1268,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   //  * the window arithmetic has its constants folded and leaves the clamping to the saturating float -> int conversion.
   auto org_search = [&](const float r_lim, const bool poll_stop, auto &&found) {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    static_assert(sizeof(S.prod) + sizeof(S.dtile) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
+    static_assert(sizeof(S.prod) + sizeof(S.dtile) + sizeof(S.stage_pad) >= (size_t)NW * ICP_STAGE_CAP * 16, "the chain tiles (idle during the search) hold every wave's staged rows");
+    static_assert(offsetof(SH, stage_pad) == offsetof(SH, dtile) + sizeof(S.dtile), "prod, dtile and stage_pad are one contiguous region");
     static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
     float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
     const float *rimg = (const float *)sref;
@@ -1939,7 +1953,7 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
   return kept_before;
 }
 
-// The model indices in 8x8-pixel tile order (tile rows alternately left-to-right and right-to-left, so consecutive tiles
+// The model indices in tile order (FL_ICP_TILE_W x 64 / FL_ICP_TILE_W pixels: 16 x 4) (tile rows alternately left-to-right and right-to-left, so consecutive tiles
 // are neighbours): the 64 queries a wave takes per step then project into a compact window of the reference image.
 // Index k of crop pixel p is idximg[p] (the paired compaction keeps the same pixels of both clouds).
 template <class SH>
@@ -1948,7 +1962,9 @@ __device__ __forceinline__ void build_tile_order(SH &S, const int *idximg, int c
   constexpr int BS = SH::BS, NW = SH::NW;
   int *cnt = (int *)&S.prod[0][0][0];
   constexpr int CAP = (int)(sizeof(S.prod) / 4);
-  const int ntx = (cw + 7) >> 3, nty = (ch + 7) >> 3, ntile = ntx * nty;
+  constexpr int TW = FL_ICP_TILE_W, TH = 64 / FL_ICP_TILE_W;
+  static_assert(TW * TH == 64 && (TW & (TW - 1)) == 0, "a tile is one wavefront of pixels");
+  const int ntx = (cw + TW - 1) / TW, nty = (ch + TH - 1) / TH, ntile = ntx * nty;
   if (ntile > CAP) {                                       // more tiles than the scratch holds (crops beyond 1.5 Mpixel): index order
     for (int i = threadIdx.x; i < n; i += BS) perm[i] = i;
     __syncthreads();
@@ -1960,7 +1976,7 @@ __device__ __forceinline__ void build_tile_order(SH &S, const int *idximg, int c
     const int ty = (int)(((float)t + 0.5f) * inv_ntx);
     int tx = t - ty * ntx;
     if (ty & 1) tx = ntx - 1 - tx;
-    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const int x = tx * TW + (lane & (TW - 1)), y = ty * TH + lane / TW;
     int k = NN_IDX_NONE;
     if (x < cw && y < ch) k = idximg[y * cw + x];
     has = (unsigned)k < (unsigned)NN_IDX_NONE;

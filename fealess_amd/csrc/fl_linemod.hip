@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_SCAN_WPE
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     const uint32_t *offs = a.offs + h.off_begin;
     // A feature's 16 bytes start at an arbitrary byte.  A byte-aligned 16-byte load costs ~2.4x a 4-byte aligned one
-    // on gfx950 (tools/dev/ldwidth.hip) and this loop is bound by exactly those loads, so each feature is fetched as
+    // on gfx950 (tools/probes/ldwidth.hip) and this loop is bound by exactly those loads, so each feature is fetched as
     // an aligned 16 + 4 bytes and shifted into place with four v_alignbyte (the misalignment is wave-uniform).
     // The extra 4 bytes are the next lane's first dword: one DPP wave shift instead of a second vector load; lane 63's
     // come from a wave-uniform address, i.e. a scalar load.

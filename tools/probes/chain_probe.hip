@@ -2,7 +2,7 @@
 // other waves of the same SIMD that issue independent VALU work, and with s_setprio raised on the chain wave?
 // (the ICP kernel's chain phases run 12 - 13 cycles per add with 4 waves per SIMD; this says how much of that is the chain's
 // own latency and how much is the issue slots the neighbours take)
-// hipcc --offload-arch=gfx950 -O2 tools/dev/chain_probe.hip -o /tmp/chain_probe && /tmp/chain_probe
+// hipcc --offload-arch=gfx950 -O2 tools/probes/chain_probe.hip -o /tmp/chain_probe && /tmp/chain_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,6 +1,6 @@
 // dev probe: how does rocprofv3's FETCH_SIZE count the access widths the ICP kernel uses?  Each kernel reads a buffer far
 // larger than the Infinity Cache exactly once; compare the counter (KiB) with the bytes printed here.
-//   hipcc --offload-arch=gfx950 -O2 tools/dev/fetch_calib.hip -o /tmp/fetch_calib
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/fetch_calib.hip -o /tmp/fetch_calib
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/fetch_calib -- /tmp/fetch_calib
 #include <hip/hip_runtime.h>
 #include <stdio.h>

@@ -1,8 +1,8 @@
 #!/bin/bash
-# dev only: FETCH_SIZE / WRITE_SIZE of tools/dev/fetch_calib.hip's kernels against the bytes they touch
+# dev only: FETCH_SIZE / WRITE_SIZE of tools/probes/fetch_calib.hip's kernels against the bytes they touch
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-hipcc --offload-arch=gfx950 -O2 tools/dev/fetch_calib.hip -o /tmp/fetch_calib 2>/dev/null || exit 1
+hipcc --offload-arch=gfx950 -O2 tools/probes/fetch_calib.hip -o /tmp/fetch_calib 2>/dev/null || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/fetch_calib_$c
   timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/fetch_calib_$c -- /tmp/fetch_calib > gpurun_out/fetch_calib_$c.log 2>&1 || { tail -3 gpurun_out/fetch_calib_$c.log; exit 1; }

@@ -1,5 +1,5 @@
 // dev probe: which SIMD does wave w of a 256-thread workgroup land on, and how do 4 co-resident workgroups of a CU line up?
-// hipcc --offload-arch=gfx950 -O2 tools/dev/simd_probe.hip -o /tmp/simd_probe && /tmp/simd_probe
+// hipcc --offload-arch=gfx950 -O2 tools/probes/simd_probe.hip -o /tmp/simd_probe && /tmp/simd_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

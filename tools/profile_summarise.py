@@ -59,7 +59,7 @@ for k, rows in rows_by_kernel.items():
         if g == gmax:
             sel[c].append(v)
             dur.append(ns)
-    kernels[f"{k} @ grid {gmax}"] = dict({c: sum(v) / len(v) for c, v in sorted(sel.items())}, launches=len(dur) // max(1, len(sel)),
+    kernels[f"{k} @ grid {gmax}"] = dict({c: sum(v) / len(v) for c, v in sorted(sel.items())}, launches=max(len(v) for v in sel.values()),
                                          duration_ns_under_pmc=sum(dur) / max(1, len(dur)))
 json.dump({
     "command": "rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --batch %d --templates %d "
