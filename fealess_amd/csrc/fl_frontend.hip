@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FL_CQ_WPE, 
 #undef PX
         dxs[ch] = dx;
         dys[ch] = dy;
-        mags[ch] = dx * dx + dy * dy;
+        mags[ch] = __mul24(dx, dx) + __mul24(dy, dy);      // |dx|, |dy| <= 1020: the full-rate 24-bit multiply
       }
       if (mags[0] >= mags[1] && mags[0] >= mags[2]) { bdx = dxs[0]; bdy = dys[0]; bmag = mags[0]; }
       else if (mags[1] >= mags[0] && mags[1] >= mags[2]) { bdx = dxs[1]; bdy = dys[1]; bmag = mags[1]; }
@@ -444,7 +444,7 @@ __device__ __forceinline__ unsigned dq_normal_pattern(const uint16_t *__restrict
 {
   const int r = 5;
   if (!(y >= r && y < h - r - 1 && x >= r && x < w - r - 1)) return dq_pattern(0);   // loop bounds :619, :624
-  const uint16_t *p = depth + (size_t)y * w + x;
+  const uint16_t *p = depth + (__umul24((unsigned)y, (unsigned)w) + (unsigned)x);   // (rows, columns < 2^24: the full-rate multiply)
   const int d = p[0];
   if (!(d < distance_threshold)) return dq_pattern(0);
   const int t = difference_threshold;
@@ -461,17 +461,20 @@ __device__ __forceinline__ unsigned dq_normal_pattern(const uint16_t *__restrict
   const int m0 = g0 ? e0 : 0, m1 = g1 ? e1 : 0, m2 = g2 ? e2 : 0, m3 = g3 ? e3 : 0, m4 = g4 ? e4 : 0, m5 = g5 ? e5 : 0,
             m6 = g6 ? e6 : 0, m7 = g7 ? e7 : 0;
   const int corners = f0 + f2 + f5 + f7;
-  const int A0 = 25 * (corners + f3 + f4), A3 = 25 * (corners + f1 + f6), A1 = 25 * ((f0 + f7) - (f2 + f5));
-  const int b0 = 5 * ((m2 + m4 + m7) - (m0 + m3 + m5)), b1 = 5 * ((m5 + m6 + m7) - (m0 + m1 + m2));
-  const int det = A0 * A3 - A1 * A1;                       // <= 22500
+  // every factor below fits 24 bits, so the products are v_mul_i32_i24 (full rate) instead of the quarter-rate 32-bit multiply
+  // the compiler has to assume: |A| <= 150, det <= 22500, and with t <= 400 |b| <= 30 * 399, |dd| < 3.0e6, d < 65536
+  const int A0 = __mul24(25, corners + f3 + f4), A3 = __mul24(25, corners + f1 + f6), A1 = __mul24(25, (f0 + f7) - (f2 + f5));
+  const int det = __mul24(A0, A3) - __mul24(A1, A1);       // <= 22500
   float nx, ny, nz;
   if (t <= 400) {
     // |b| <= 30 * 399, |dd| <= 250 * |b| < 3.0e6: 617 * dd and det * d (<= 22500 * 65535) fit in int32
-    const int ddx = A3 * b0 - A1 * b1, ddy = -A1 * b0 + A0 * b1;
-    nx = (float)(617 * ddx);
-    ny = (float)(617 * ddy);
-    nz = (float)(-(det * d));
+    const int b0 = __mul24(5, (m2 + m4 + m7) - (m0 + m3 + m5)), b1 = __mul24(5, (m5 + m6 + m7) - (m0 + m1 + m2));
+    const int ddx = __mul24(A3, b0) - __mul24(A1, b1), ddy = __mul24(A0, b1) - __mul24(A1, b0);
+    nx = (float)__mul24(617, ddx);
+    ny = (float)__mul24(617, ddy);
+    nz = (float)(-__mul24(det, d));
   } else {
+    const int b0 = 5 * ((m2 + m4 + m7) - (m0 + m3 + m5)), b1 = 5 * ((m5 + m6 + m7) - (m0 + m1 + m2));
     const long long ddx = (long long)A3 * b0 - (long long)A1 * b1, ddy = -(long long)A1 * b0 + (long long)A0 * b1;
     nx = (float)(617LL * ddx);
     ny = (float)(617LL * ddy);
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256) void k_depth_quantize(const uint16_t *__restri
     const unsigned to = ((s3 >> 4) & 0x0F0F0F0Fu) + ((s2 >> 4) & 0x0F0F0F0Fu) + 0x73737373u;
     const int idx = 8 - __popc((te & 0x80808080u) | ((to & 0x80808080u) >> 1));
     const int yo = yv - 2;
-    if (lane >= 2 && lane < 2 + DQ_COLS && x < w) dst[(size_t)yo * w + x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
+    if (lane >= 2 && lane < 2 + DQ_COLS && x < w) dst[__umul24((unsigned)yo, (unsigned)w) + (unsigned)x] = idx ? (uint8_t)(1u << (idx - 1)) : 0;
   }
 }
 
