@@ -63,6 +63,7 @@ static const FlOptionName fl_option_names[] = {
   {"icp_wide", "FL_ICP_WIDE", &fl_context::Options::icp_wide, false},
   {"icp_occ", "FL_ICP_OCC", &fl_context::Options::icp_occ, false},
   {"icp_order", "FL_ICP_ORDER", &fl_context::Options::icp_order, false},
+  {"icp_wg_per_cu", "FL_ICP_WG_PER_CU", &fl_context::Options::icp_wg_per_cu, false},
   {"eager_frontend", "FL_EAGER_FRONTEND", &fl_context::Options::eager_frontend, false},
   {"dev_poison", "FL_DEV_POISON", &fl_context::Options::dev_poison, false},
   {"ws_pad", "FL_DEV_WS_PAD", &fl_context::Options::ws_pad, false},

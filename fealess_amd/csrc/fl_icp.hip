@@ -2377,16 +2377,24 @@ template <int BS, typename K>
 static int icp_launch_one(fl_context *ctx, K kern, int n_jobs, const IcpArgs &a)
 {
 #ifdef FL_ICP_LDS_PAD                                      // dev builds: extra dynamic LDS per workgroup = fewer workgroups per CU (occupancy experiment)
-  const size_t lds = ((sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15) + (BS == ICP_BS_SMALL ? (size_t)(FL_ICP_LDS_PAD) : 0);
+  size_t lds = ((sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15) + (BS == ICP_BS_SMALL ? (size_t)(FL_ICP_LDS_PAD) : 0);
 #else
-  const size_t lds = (sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15;
+  size_t lds = (sizeof(IcpSharedT<BS>) + 15) & ~(size_t)15;
 #endif
+  // option icp_wg_per_cu = 1 .. 3: no more than that many 256-thread workgroups per CU (the launch asks for so much LDS that
+  // one more does not fit) -- leaves registers and LDS to the kernels of ANOTHER stream (a second pipeline's LINEMOD stages)
+  const long cap = ctx->opt.icp_wg_per_cu;
+  if (BS == ICP_BS_SMALL && cap >= 1 && cap <= 3) {
+    const size_t want = ((size_t)(160 * 1024) / (size_t)cap - 256) & ~(size_t)15;
+    if (want > lds) lds = want;
+  }
+  const size_t attr = lds > (size_t)(82 * 1024) ? lds : (size_t)(82 * 1024);
   {                                                        // the attribute is set once per kernel and device, not per launch
     static std::mutex mu;
     static std::set<std::pair<const void *, int>> done;
     std::lock_guard<std::mutex> lock(mu);
     if (!done.count({(const void *)kern, ctx->device})) {
-      FL_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      FL_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(attr > (size_t)(160 * 1024) ? (size_t)(160 * 1024) : attr)));
       done.insert({(const void *)kern, ctx->device});
     }
   }
@@ -2641,7 +2649,7 @@ int fl_launch_detection_jobs(fl_detector *det, int n_jobs, const FlRefineJob *d_
 int fl_icp_prepare(fl_detector *det)
 {
   fl_context *ctx = det->ctx;
-  if (det->max_batch > 4 * ctx->cus && det->max_batch <= ICP_ORDER_MAX && !det->d_icp_order)
+  if (det->max_batch > 4 * ctx->cus && !det->d_icp_order)      // (used for batches of up to ICP_ORDER_MAX frames)
     FL_HIP(ctx, hipMalloc((void **)&det->d_icp_order, sizeof(int) * 2 * (size_t)det->max_batch));
   FL_HIP(ctx, hipFuncSetAttribute((const void *)k_icp_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * ICP_ORDER_MAX)));
   return FL_OK;

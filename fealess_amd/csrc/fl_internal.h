@@ -31,6 +31,8 @@ struct fl_context {
     long icp_wide = -1;         // FL_ICP_WIDE: -1 by batch size, 0 / 1 force the 256- / 1024-thread ICP kernel
     long icp_occ = 0;           // FL_ICP_OCC: 0 by batch size, 4 / 5 force the 256-thread parity kernel built for 4 / 5 workgroups per CU
     long icp_order = 1;         // FL_ICP_ORDER: ICP jobs dealt longest first
+    long icp_wg_per_cu = 0;     // FL_ICP_WG_PER_CU: 0 = as many 256-thread ICP workgroups per CU as fit (4); 1 .. 3 = at most that many, the
+                                // rest of the CU left to kernels of other streams (two pipelines on one GPU)
     long eager_frontend = 0;    // FL_EAGER_FRONTEND: finer pyramid levels in full before the scan (read by fl_detector_finalize)
     long dev_poison = 0;        // FL_DEV_POISON: fill what the lazy path leaves uncomputed with 0xFF (read by fl_detector_finalize)
     long ws_pad = 0;            // FL_DEV_WS_PAD: extra bytes of frame workspace stride (read by fl_detector_finalize)

@@ -142,10 +142,11 @@ fl_context *fl_detector_get_context(fl_detector *det);
  * every feature everywhere, as the reference does), "scan_prune_mid" (bit mask of the 8-feature groups after which a modality
  * checks the pruning bound; -1 = built-in), "icp_wide" (-1 = by batch size; 0 / 1 force the 256- / 1024-thread ICP workgroup),
  * "icp_occ" (0 = by batch size; 4 / 5 force the 256-thread kernel built for that many workgroups per CU), "icp_order" (1 = ICP
- * jobs dealt longest first; 0 = frame order), and -- sampled by fl_detector_finalize -- "eager_frontend" (1 = finer pyramid
+ * jobs dealt longest first; 0 = frame order), "icp_wg_per_cu" (0 = as many 256-thread ICP workgroups per CU as fit; 1 .. 3 = at
+ * most that many, the rest of the CU left to the kernels of other streams), and -- sampled by fl_detector_finalize -- "eager_frontend" (1 = finer pyramid
  * levels in full before the scan, the reference's order), "dev_poison" (1 = what the lazy path leaves uncomputed is filled
  * with 0xFF), "ws_pad" (extra bytes of frame-workspace stride).  Their INITIAL values are read once from the environment
- * when the context is created (FL_SCAN_PRUNE, FL_SCAN_PRUNE_MID (hex), FL_ICP_WIDE, FL_ICP_OCC, FL_ICP_ORDER,
+ * when the context is created (FL_SCAN_PRUNE, FL_SCAN_PRUNE_MID (hex), FL_ICP_WIDE, FL_ICP_OCC, FL_ICP_ORDER, FL_ICP_WG_PER_CU,
  * FL_EAGER_FRONTEND, FL_DEV_POISON, FL_DEV_WS_PAD); nothing reads the environment after that, so a variable set in a host
  * process later on changes nothing.  Unknown names: FL_ERR_INVALID. */
 int  fl_context_set_option(fl_context *ctx, const char *name, long value);
