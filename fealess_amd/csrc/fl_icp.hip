@@ -102,6 +102,11 @@
                                   // per CU nobody waits for the chain, and a phase B that runs as fast as memory lets it only takes the
                                   // memory side from the co-resident workgroups' phases); 0: always term by term
 #endif
+#ifndef FL_ICP_ZIMG
+#define FL_ICP_ZIMG 1             // organised search, parity mode: the staged rectangles and the partner gather read a 4-byte image (the
+                                  // pixel's depth factor, NaN where the pixel was dropped) and rebuild the 12-byte point by crop_clouds'
+                                  // own expression -- bit for bit the point the 12-byte image holds -- instead of reading it
+#endif
 #ifndef FL_ICP_TILE_W
 #define FL_ICP_TILE_W 16          // organised search: the queries of a step come from FL_ICP_TILE_W x (64 / FL_ICP_TILE_W)-pixel tiles.  Wider tiles =
                                   // longer contiguous runs in the tile-ordered gathers / scatters (mod, bnd, nn: 192 instead of 96 bytes per row piece)
@@ -134,6 +139,8 @@
 //   sref  (n+4) x 16 bytes.  grid search: reference cloud sorted by grid cell as float4 (index bits, X, Y, Z);
 //                     organised search: the reference IMAGE, crop pixel p -> X, Y, Z (3 x f32; +inf where the pixel was
 //                     dropped by the paired compaction), then the image of the points' indices (i32, NN_IDX_NONE where dropped)
+//   zimg   (n+4) x f32  organised search: crop pixel p -> rescaleDepth's z factor of the scene pixel (depth * (1 / 1000.0)), NaN where
+//                     the paired compaction dropped the pixel: the point is (((sx - cx) / fx... crop_clouds' expression) of it
 //   nn     n x i32    nearest reference point j of model point i (kept pair: j, dropped: -1): its index (grid search) or its
 //                     crop pixel (organised search)
 //   bnd    n x 16 bit upper bound on the distance from model point i to its nearest reference point: the top half of the
@@ -145,7 +152,7 @@
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid (grid search)
 //   nrm   n x 3 f32   unit normals of the reference cloud, index order (FL_ICP_POINT_TO_PLANE only; 0 = unknown)
 struct IcpWsLayout {
-  size_t ref, mod, sref, nn, bnd, nd, dterm, perm, cell_start, cell_cur, nrm, total;
+  size_t ref, mod, sref, zimg, nn, bnd, nd, dterm, perm, cell_start, cell_cur, nrm, total;
   int ncell_max;
 };
 static __host__ __device__ inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -157,6 +164,7 @@ static __host__ __device__ inline IcpWsLayout icp_layout(int n)
   L.ref = o; o = al256(o + 12 * nn);
   L.mod = o; o = al256(o + 12 * nn);
   L.sref = o; o = al256(o + 16 * (nn + 4));          // + NN_OVERRUN points at infinity behind the reference image
+  L.zimg = o; o = al256(o + 4 * (nn + 4));           // organised search: crop pixel -> depth factor (float), + the overrun guard
   L.nn = o; o = al256(o + 4 * nn);
   L.bnd = o; o = al256(o + 4 * nn);
   L.nd = o; o = al256(o + 4 * nn);
@@ -889,7 +897,35 @@ struct OrgGeom {
   float offu, offv;      // scene pixel of crop pixel (0, 0) minus the principal point
   float fx, fy;
   float cwm, chm;        // (float)(cw - 1), (float)(ch - 1)
+  int sx0, sy0;          // scene pixel of crop pixel (0, 0)
+  float cx, cy, inv_fx, inv_fy;   // as crop_clouds uses them: (float)K.cx, 1.0f / (float)K.fx ...
 };
+// The reference point of crop pixel (u, v) from its depth factor zsf, by crop_clouds' own expression (depth_to_3d.cpp:119,132 +
+// scale_mat_vec3f): bit for bit what the 12-byte image holds.  A dropped pixel (zsf = NaN) gives a NaN point, whose distance
+// is NaN: its key orders behind every real one.
+// element of the depth-factor image: the factor itself (float, NaN = dropped) or (FL_ICP_ZIMG == 2) the scene's 16-bit depth
+// (0 = dropped, which rescaleDepth turns into NaN anyway: depth_to_3d.cpp:257-259)
+#if FL_ICP_ZIMG == 2
+typedef uint16_t zimg_t;
+__device__ __forceinline__ float zimg_ld(const zimg_t *__restrict__ z, int i)
+{
+  const unsigned d = ld_u32(z, i);
+  return d == 0 ? NAN : (float)d * (float)(1 / 1000.0);
+}
+__device__ __forceinline__ zimg_t zimg_pack(bool keep, unsigned ds, float) { return (zimg_t)(keep ? ds : 0u); }
+#else
+typedef float zimg_t;
+__device__ __forceinline__ float zimg_ld(const zimg_t *__restrict__ z, int i) { return ld_u32(z, i); }
+__device__ __forceinline__ zimg_t zimg_pack(bool keep, unsigned, float zsf) { return keep ? zsf : NAN; }
+#endif
+__device__ __forceinline__ F3 org_point(const OrgGeom &g, int u, int v, float zsf)
+{
+  F3 p;
+  p.x = ((((float)(g.sx0 + u) - g.cx) * g.inv_fx) * zsf) * 1000;
+  p.y = ((((float)(g.sy0 + v) - g.cy) * g.inv_fy) * zsf) * 1000;
+  p.z = zsf * 1000;
+  return p;
+}
 // whole-wave minimum / maximum of an int by DPP (row_shr 1, 2, 4, 8, row_bcast 15 / 31), returned as a wave-uniform value
 #define FL_DPP_RED(OP, IDENT)                                                                                 \
   v = OP(v, __builtin_amdgcn_update_dpp((int)(IDENT), v, 0x111, 0xF, 0xF, false));                            \
@@ -1273,6 +1309,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     static_assert(offsetof(SH, dtile) == offsetof(SH, prod) + sizeof(S.prod), "prod and dtile are one contiguous region");
     float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
     const float *rimg = (const float *)sref;
+    // (the 1024-thread kernel keeps the 12-byte image: a frame alone on its CU waits for the rebuilt points -- 2.92 against 2.67 ms
+    // per 8 frames -- where four workgroups per CU gain from the bytes: 32.9 against 34.2 ms per 4096)
+    constexpr bool ZIMG = FL_ICP_ZIMG && MODE == FL_ICP_PARITY && NW < 8;
+    const zimg_t *zimg = (const zimg_t *)(wsb + L.zimg);
     const int last_s = n_model - 1;
     const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
     constexpr int stride = NW * 64;
@@ -1375,8 +1415,16 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
             for (int p = 0; p < NP; ++p) {
               const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
               const int pos = min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
-              const F3 pt = ld3_u32(rimg, pos);
-              R[p] = nn_point(pt.x, pt.y, pt.z, pt.x == INFINITY ? NN_IDX_NONE : pos);
+              if (ZIMG) {
+                // 4 bytes per staged point instead of 12: the pixel's depth factor; its point rebuilt by crop_clouds' expression
+                // (pixel (U0 + col, V0 + row); a slot clamped to the guard behind the image reads NaN whatever its pixel)
+                const float zf = zimg_ld(zimg, pos);
+                const F3 pt = org_point(og, U0 + col, V0 + row, zf);
+                R[p] = nn_point(pt.x, pt.y, pt.z, zf != zf ? NN_IDX_NONE : pos);
+              } else {
+                const F3 pt = ld3_u32(rimg, pos);
+                R[p] = nn_point(pt.x, pt.y, pt.z, pt.x == INFINITY ? NN_IDX_NONE : pos);
+              }
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) stage[lane + 64 * p] = R[p];
@@ -1607,8 +1655,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         int j;                                             // nearest reference index (valid from the gather on)
         float d;                                           // SPEC: its squared distance
         bool in;                                           // the row exists (below `rows`)
-        F3 m, r;                                           // model point, reference point
+        F3 m, r;                                           // model point, reference point (FL_ICP_ZIMG: r.x = its depth factor until row_write)
       };
+      constexpr bool ZIMG = FL_ICP_ZIMG && ORG && NW < 8;
+      const zimg_t *zimg = (const zimg_t *)(wsb + L.zimg);
       auto row_load = [&](Row &w, int t) {                 // issue only: nothing here reads what it loads
         const int i = t * TQ + slot;
         w.in = i < rows;
@@ -1619,14 +1669,20 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       };
       auto row_gather = [&](Row &w) {                      // SPEC: nn[] holds the neighbour whatever its distance; the pair is kept
         if (!(w.in && (!SPEC || w.d <= thr))) w.j = -1;    // if d <= dist_thr (:268; NaN = none found)
-        w.r = ld3_u32(jsrc, max(w.j, 0));
+        if (ZIMG) w.r.x = zimg_ld(zimg, max(w.j, 0));      // 4 (2) bytes: the partner pixel's depth factor (rebuilt in row_write)
+        else w.r = ld3_u32(jsrc, max(w.j, 0));
       };
       auto row_write = [&](const Row &w, int t) {
         const bool have = w.j >= 0;                        // dropped pairs contribute an exact +0.0f: (+0) * (+0)
         if (SPEC && have) ++kept;
         float (*tile)[SH::TS] = S.prod[t & 1];
+        F3 rp = w.r;
+        if (ZIMG) {                                        // the partner's point from its pixel and depth factor (org_point)
+          const int jj = max(w.j, 0), vv = jj / og.cw;
+          rp = org_point(og, jj - vv * og.cw, vv, w.r.x);
+        }
         const float mm[3] = {have ? w.m.x : 0.0f, have ? w.m.y : 0.0f, have ? w.m.z : 0.0f};
-        const float rr[3] = {have ? w.r.x : 0.0f, have ? w.r.y : 0.0f, have ? w.r.z : 0.0f};
+        const float rr[3] = {have ? rp.x : 0.0f, have ? rp.y : 0.0f, have ? rp.z : 0.0f};
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1886,7 +1942,7 @@ __device__ __forceinline__ void scene_normal(const uint16_t *__restrict__ scene,
 
 template <class SH>
 __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16_t *scene, const uint16_t *model, bool model_01mm,
-                           const int *rm, const int *rr, float *ref, float *mod, float *nrm, float *rimg, int *idximg)
+                           const int *rm, const int *rr, float *ref, float *mod, float *nrm, float *rimg, int *idximg, zimg_t *zimg)
 {
   constexpr int BS = SH::BS, NW = SH::NW;
   const int cw = rm[2], ch = rm[3], np = cw * ch;
@@ -1902,6 +1958,8 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
   for (int base = 0; base < np; base += BS, ++step) {
     const int p = base + threadIdx.x;
     float A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
+    float zsf_keep = NAN;                                   // the scene pixel's depth factor (what org_point rebuilds A from)
+    unsigned ds_keep = 0;
     int keep = 0;
     if (p < np) {
       const int y = np < (1 << 20) && cw <= 1024 ? (int)(((float)p + 0.5f) * inv_cw) : p / cw, x = p - y * cw;
@@ -1913,6 +1971,8 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
         dm = (unsigned)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
       }
       const float zsf = ds == 0 ? NAN : (float)ds * zs;                           // rescaleDepth :257-259
+      zsf_keep = zsf;
+      ds_keep = ds;
       const float zmf = dm == 0 ? NAN : (float)dm * zs;
       A[0] = ((((float)sx - a.cx) * inv_fx) * zsf) * 1000;                        // :119,:132; scale_mat_vec3f
       A[1] = ((((float)sy - a.cy) * inv_fy) * zsf) * 1000;
@@ -1935,6 +1995,7 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
       const F3 pt = {keep ? A[0] : INFINITY, keep ? A[1] : INFINITY, keep ? A[2] : INFINITY};
       __builtin_memcpy(rimg + 3 * p, &pt, 12);
       idximg[p] = keep ? kept_before + before + in_wave : NN_IDX_NONE;
+      if (zimg) zimg[p] = zimg_pack(keep, ds_keep, zsf_keep);
     }
     if (keep) {
       const int k = kept_before + before + in_wave;
@@ -1949,6 +2010,7 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
     kept_before += total;
   }
   if (threadIdx.x < 3 * NN_OVERRUN) rimg[3 * np + threadIdx.x] = INFINITY;     // overrun guard: points at infinity behind the image (org_scan)
+  if (zimg && threadIdx.x < NN_OVERRUN + 1) zimg[np + threadIdx.x] = zimg_pack(false, 0u, NAN);
   __syncthreads();                                         // the clouds are complete for every thread
   return kept_before;
 }
@@ -2079,7 +2141,7 @@ __global__ __launch_bounds__(BS) void k_icp_clouds(IcpArgs a)
   SH &S = *(SH *)icp_smem;
   const IcpWsLayout L = icp_layout(a.n_max);
   uint8_t *wsb = a.ws + (size_t)blockIdx.x * a.ws_stride;
-  const OrgGeom none = {0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const OrgGeom none = {0, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0.f, 0.f, 0.f, 0.f};
   chain_elect(S, nullptr);
   icp_run<MODE, false>(S, wsb, L, a.job.n_ref, a.job.n_model, a.it_thr, a.dmt, a.ddt, &a.results[blockIdx.x].det.icp, none);
 }
@@ -2171,11 +2233,14 @@ void k_icp_pipeline(IcpArgs a)
   float *rimg = (float *)(wsb + L.sref);                  // image of 12-byte points, then the image of their indices (16 bytes per pixel in all)
   const int np = crop_clouds(S, a, scene, model, model_01mm, S.rect_m, S.rect_r, ref, mod,
                              MODE == FL_ICP_POINT_TO_PLANE ? (float *)(wsb + L.nrm) : nullptr, rimg,
-                             (int *)((uint8_t *)rimg + org_idximg_offset(S.rect_m[2] * S.rect_m[3])));
+                             (int *)((uint8_t *)rimg + org_idximg_offset(S.rect_m[2] * S.rect_m[3])),
+                             FL_ICP_ZIMG && MODE == FL_ICP_PARITY && BS < ICP_BS_WIDE ? (zimg_t *)(wsb + L.zimg) : nullptr);
   // wave-uniform values read from LDS are VGPRs unless told otherwise: the search loop keeps them in SGPRs
   const OrgGeom og = {__builtin_amdgcn_readfirstlane(S.rect_r[2]), __builtin_amdgcn_readfirstlane(S.rect_r[3]),
                       uniform_f((float)S.rect_r[0] - a.cx), uniform_f((float)S.rect_r[1] - a.cy), a.fx, a.fy,
-                      uniform_f((float)(S.rect_r[2] - 1)), uniform_f((float)(S.rect_r[3] - 1))};
+                      uniform_f((float)(S.rect_r[2] - 1)), uniform_f((float)(S.rect_r[3] - 1)),
+                      __builtin_amdgcn_readfirstlane(S.rect_r[0]), __builtin_amdgcn_readfirstlane(S.rect_r[1]), a.cx, a.cy,
+                      uniform_f(1.0f / a.fx), uniform_f(1.0f / a.fy)};
   build_tile_order(S, (const int *)((const uint8_t *)rimg + org_idximg_offset(og.cw * og.ch)), og.cw, og.ch, np, (int *)(wsb + L.perm));
   // getMean x2 (detection.cpp:165-166), t_match_tmp = r - m (:177), t_init (:199)
   float mc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};

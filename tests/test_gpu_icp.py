@@ -603,7 +603,7 @@ def test_large_batch_jobs_dealt_longest_first_keep_their_results(ctx, oracle):
     """A batch above four frames per CU hands the ICP launch its jobs longest first (k_icp_count + k_icp_order: workgroup b
     runs job order[b]).  The order is scheduling only: every frame's result must be what the same frame gives alone, and what
     the batch gives in frame order (option icp_order = 0), bit for bit -- frames of different cloud sizes, so that the order is a
-    real permutation.  Also the exact pruning of the scan (option scan_prune = 0 / 1): same matches either way."""
+    real permutation.  Also the exact pruning of the scan (option scan_prune = 0 / 1) and a capped ICP occupancy (icp_wg_per_cu): same results either way."""
     import torch
     scenes = [synth.recognition_scene(lambda b, d, l: oracle.quantize_pyramid(b, d, l), levels=2, seed=s, n_views=3) for s in (3, 5)]
     sc = scenes[0]
@@ -628,13 +628,15 @@ def test_large_batch_jobs_dealt_longest_first_keep_their_results(ctx, oracle):
     single = det.recognize_batch(frames_b, frames_d, sc["K"], 75.0, 8, 0.0, -3.0e38)
     assert sum(r["found"] for r in single) >= 3 and len({r["det"]["n_points"] for r in single if r["found"]}) >= 2
     runs = {}
-    for tag, opts in (("longest_first", {}), ("frame_order", {"icp_order": 0}), ("unpruned", {"scan_prune": 0})):
+    for tag, opts in (("longest_first", {}), ("frame_order", {"icp_order": 0}), ("unpruned", {"scan_prune": 0}),
+                      ("three_workgroups_per_cu", {"icp_wg_per_cu": 3})):
+        before = {k_: ctx.get_option(k_) for k_ in opts}
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         det.recognize_submit_device(bp, dp, sc["K"], params)
         runs[tag] = [api.recognition_result_to_dict(r) for r in det.recognize_collect(n)]
-        for k_ in opts:
-            ctx.set_option(k_, 1)
+        for k_, v_ in before.items():
+            ctx.set_option(k_, v_)
     for tag, res in runs.items():
         for i in range(n):
             e, g = single[order[i]], res[i]
