@@ -60,3 +60,19 @@ def test_opencv_adapter_header_is_well_formed():
               "-I", CAD, os.path.join(SRC, "tu_adapter_syntax.cpp")])
     assert r.returncode == 0, r.stdout
     assert "warning" not in r.stdout, r.stdout
+
+
+def test_cxx_caller_of_the_multi_gpu_host_compiles_and_links(tmp_path):
+    """include/fealess_mg.h from C++ (north_star: "host code stays C++"): a translation unit that uses every entry point compiles
+    with g++ against the header alone and links libfealess_mg.so (which brings in librccl and libfealess_hip.so); run here it
+    only reaches the argument checks -- the collectives run on the GPU box (tests/test_gpu_configs.py)."""
+    exe = str(tmp_path / "tu_mg")
+    MG = os.path.join(ROOT, "fealess_amd", "mg")
+    r = _run(["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), os.path.join(SRC, "tu_mg_caller.cpp"), "-o", exe,
+              "-L", MG, "-lfealess_mg", "-Wl,-rpath," + MG, "-Wl,-rpath," + os.path.join(ROOT, "fealess_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib"])
+    assert r.returncode == 0, r.stdout
+    out = _run([exe])
+    assert out.returncode == 0, out.stdout
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines() if " " in l)
+    assert lines["create_null_detector"] == "-1 1" and lines["unique_id_short_buffer"] == "-1" and lines["recognize_null_group"] == "-1"
+    assert lines["sizeof_result"] == "92"
