@@ -1493,6 +1493,163 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   // step's rectangle fetched by LDS-DMA while this one is scanned -- shortens the search phase by a fifth and lengthens the
   // chain phases by as much; the rectangle staged as 2-byte depths with the points rebuilt in registers, an eighth of the
   // staged bytes, is slower still: the conversion sits on the step's critical path.)
+  // ---- the same search with the staging one step ahead (256-thread parity kernel) -------------------------------------------
+  // With the 4-byte image a step's staged data is a handful of dwords per lane, so the NEXT step can be prepared -- its
+  // windows, its union rectangle, its staging loads issued -- before this step is scanned: the loads' round trip (a third of a
+  // step) runs underneath the scan instead of in front of it.  Two prepared-step states trade roles by unrolling the loop
+  // twice (never by moves: see the chain phases); a state always issues ICP_PIPE_NP loads (slots past its rectangle read the
+  // guard behind the image), so the instruction stream between issue and use has no branch that would make the compiler drain
+  // the queue.  Same windows, same candidates, same keys: bit-identical to org_search.
+#ifndef FL_ICP_PIPE
+#define FL_ICP_PIPE 1
+#endif
+#define ICP_PIPE_NP 6
+
+  struct Prep {
+    int i;                                   // the lane's query (model index) and point
+    float qx, qy, qz;
+    bool active, queryable;
+    int u_lo, u_hi, v_lo, v_hi;              // its window (one pixel of the union if it has none)
+    int U0, V0, W, maxh, nbw, npass;         // wave-uniform: union rectangle, tallest window, batches per row, passes
+    bool any, staged;
+    float z[ICP_PIPE_NP];                    // depth factors of the staged slots lane + 64 p (in flight until finish)
+  };
+  auto org_search_pipe = [&](const float r_lim, auto &&found) {
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    float4 *stage = (float4 *)&S.prod[0][0][0] + wv * ICP_STAGE_CAP;
+    const float *rimg = (const float *)sref;
+    const zimg_t *zimg = (const zimg_t *)(wsb + L.zimg);
+    const int last_s = n_model - 1, last_pt = og.cw * og.ch + NN_OVERRUN - 1;
+    const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
+    constexpr int stride = NW * 64;
+    // windows, union and staging loads of the step whose queries start at sb
+    auto prepare = [&](Prep &P, int sb, int i, const F3 &q, float b) {
+      P.i = i; P.qx = q.x; P.qy = q.y; P.qz = q.z;
+      P.active = sb + lane < n_model;
+      P.queryable = P.active && r_lim >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
+      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
+      bool some = false;
+      if (P.queryable) some = org_window2(og, cul, cuh, cvl, cvh, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_lim)), u_lo, u_hi, v_lo, v_hi);
+      const int big = 0x3fffffff;
+      int red[5] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0};
+      wave_max_multi(red);
+      const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3];
+      P.maxh = red[4];
+      P.any = U1 >= U0;
+      if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }
+      P.u_lo = u_lo; P.u_hi = u_hi; P.v_lo = v_lo; P.v_hi = v_hi;
+      const int wl = u_hi - u_lo;
+      int nbw = 1;
+      if (P.any && __ballot(wl > 3) != 0ull) nbw = __ballot(wl > 7) == 0ull ? 2 : (wave_max_i(wl) >> 2) + 1;
+      P.nbw = nbw;
+      const int W = P.any ? U1 - U0 + 1 : 1, H = P.any ? V1 - V0 + 1 : 1, area = W * H;
+      const int npneed = (area + 3 + 63) >> 6;
+      P.npass = npneed <= 2 ? 2 : npneed;
+      P.staged = P.any && npneed <= ICP_PIPE_NP;
+      P.U0 = P.any ? U0 : 0; P.V0 = P.any ? V0 : 0; P.W = W;
+      const float invW = uniform_f(__builtin_amdgcn_rcpf((float)W));
+      const int base = (int)__umul24((unsigned)P.V0, (unsigned)og.cw) + P.U0;
+      const int np_eff = P.staged ? P.npass : 0;               // passes that hold the rectangle; the others read the guard
+#pragma unroll
+      for (int p = 0; p < ICP_PIPE_NP; ++p) {
+        const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
+        const int pos = min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
+        P.z[p] = zimg_ld(zimg, p < np_eff ? pos : last_pt);
+      }
+    };
+    // the step itself: rebuild and stage its rectangle, scan, unpack
+    auto finish = [&](const Prep &P, int &j, float &d) {
+      j = -1;
+      d = NAN;
+      if (!P.any) return;
+      const float qx = P.qx, qy = P.qy, qz = P.qz;
+      const int u_lo = P.u_lo, u_hi = P.u_hi, v_lo = P.v_lo, v_hi = P.v_hi, W = P.W, U0 = P.U0, V0 = P.V0, maxh = P.maxh, nbw = P.nbw;
+      const int wl = u_hi - u_lo, hl = v_hi - v_lo;
+      unsigned long long best = NN_KEY_NONE;
+      if (P.staged) {
+        const float invW = uniform_f(__builtin_amdgcn_rcpf((float)W));
+        const int base = (int)__umul24((unsigned)V0, (unsigned)og.cw) + U0;
+        auto put = [&](int p) {
+          const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
+          const int pos = min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
+          const float zf = P.z[p];
+          const F3 pt = org_point(og, U0 + col, V0 + row, zf);
+          stage[lane + 64 * p] = nn_point(pt.x, pt.y, pt.z, zf != zf ? NN_IDX_NONE : pos);
+        };
+        put(0);
+        put(1);
+        if (P.npass > 2) put(2);
+        if (P.npass > 3) put(3);
+        if (P.npass > 4) { put(4); put(5); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 *row0 = stage + (v_lo - V0) * W + (u_lo - U0);
+        if (nbw == 1) {
+          for (int dv = 0; dv < maxh; ++dv) {
+            const float4 *bp = row0 + min(dv, hl) * W;
+            float4 cur[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[e] = bp[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+          }
+        } else {
+          const int wlc = max(wl - 3, 0);
+          for (int dv = 0; dv < maxh; ++dv) {
+            const float4 *rowp = row0 + min(dv, hl) * W;
+            for (int du = 0; du < 4 * nbw; du += 4) {
+              const float4 *bp = rowp + min(du, wlc);
+              float4 cur[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) cur[e] = bp[e];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) NN_CONSIDER(cur[e])
+            }
+          }
+        }
+      } else {
+        best = org_scan([&](int idx) { const F3 pt = ld3_u32(rimg, idx); return nn_point(pt.x, pt.y, pt.z, pt.x == INFINITY ? NN_IDX_NONE : idx); },
+                        og.cw, 0, 0, qx, qy, qz, u_lo, u_hi, v_lo, v_hi, 4 * nbw, maxh);
+      }
+      if (P.queryable) NN_UNPACK(best, &j, &d)
+    };
+    int sb0 = wv * 64, sb1 = sb0 + stride, sb2 = sb0 + 2 * stride, sb3 = sb0 + 3 * stride;
+    if (!(sb0 < n_model)) return;
+    int i_c = ld_u32(perm, min(sb0 + lane, last_s));
+    int i_n = ld_u32(perm, min(sb1 + lane, last_s));
+    int i_nn = ld_u32(perm, min(sb2 + lane, last_s));
+    F3 q_c = ld3_u32(mod, i_c), q_n = ld3_u32(mod, i_n);
+    float b_c = bnd_ld(bnd, i_c), b_n = bnd_ld(bnd, i_n);
+    Prep A, B;
+    prepare(A, sb0, i_c, q_c, b_c);
+    bool pend = false, p_active = false;
+    int p_i = 0, p_j = -1;
+    float p_qx = 0.f, p_qy = 0.f, p_qz = 0.f, p_d = NAN;
+    // one step: the results of the step before are stored, the queries of the step after next requested, the NEXT step prepared
+    // (its loads issued), then THIS step finished
+#define ICP_PIPE_STEP(CUR, NXT)                                                                                        \
+    {                                                                                                                  \
+      if (pend) { found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d); pend = false; }                                    \
+      const F3 q_nn = ld3_u32(mod, i_nn);                                                                              \
+      const float b_nn = bnd_ld(bnd, i_nn);                                                                            \
+      const int i_nnn = ld_u32(perm, min(sb3 + lane, last_s));                                                         \
+      prepare(NXT, sb1, i_n, q_n, b_n);                                                                                \
+      int j_; float d_;                                                                                                \
+      finish(CUR, j_, d_);                                                                                             \
+      pend = true; p_active = CUR.active; p_i = CUR.i; p_qx = CUR.qx; p_qy = CUR.qy; p_qz = CUR.qz; p_j = j_; p_d = d_; \
+      i_n = i_nn; q_n = q_nn; b_n = b_nn; i_nn = i_nnn;                                                                \
+      sb0 = sb1; sb1 = sb2; sb2 = sb3; sb3 += stride;                                                                  \
+    }
+    for (;;) {
+      ICP_PIPE_STEP(A, B)
+      if (!(sb0 < n_model)) break;
+      ICP_PIPE_STEP(B, A)
+      if (!(sb0 < n_model)) break;
+    }
+#undef ICP_PIPE_STEP
+    if (pend) found(p_active, p_i, p_qx, p_qy, p_qz, p_j, p_d);
+  };
 #define ORG_SEARCH org_search
   // the deferred dist_mean chain of the pending distances (chain wave), then -- every wave -- the search for the next iteration
   auto chain_and_search = [&](const int pend, const bool want, const float r_lim, const float old_mean_) {
@@ -1594,8 +1751,8 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       // cloud visits only a handful of candidates per point; the result is still the exact 1-NN.
       const float r_thr = uniform_f(sqrtf(thr));
       if (ORG) {
-        if (!SPEC)
-          ORG_SEARCH(r_thr, false, [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
+        constexpr bool PIPE = FL_ICP_PIPE && FL_ICP_ZIMG && MODE == FL_ICP_PARITY && NW < 8;
+        auto on_found = [&](bool active, int i, float qx, float qy, float qz, int j, float d) {
             const bool keep = d <= thr;                       // dists[i][0] <= dist_thr (:268)
             if (active) {
               nn[i] = keep ? j : -1;
@@ -1605,7 +1762,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
               ++kept;
               if (!parity) { const F3 rv = ld3_u32(jsrc, j); pair_sums(qx, qy, qz, rv.x, rv.y, rv.z, j); }
             }
-          });
+          };
+        if (!SPEC) {
+          if (PIPE) org_search_pipe(r_thr, on_found);
+          else ORG_SEARCH(r_thr, false, on_found);
+        }
       } else {
         const NnGrid G = nn_grid(S);
         int i = threadIdx.x;
