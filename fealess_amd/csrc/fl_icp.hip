@@ -621,7 +621,9 @@ struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 ld3_u32(const float *__restrict__ base, int i)
 {
   F3 v;
-  __builtin_memcpy(&v, (const char *)base + (size_t)((unsigned)i * 12u), 12);
+  unsigned i3;                                           // 12 i as (2 i + i) << 2: the compiler folds the C form back into a quarter-rate v_mul_lo_u32
+  asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(i3) : "v"(i));
+  __builtin_memcpy(&v, (const char *)base + (size_t)(i3 << 2), 12);
   return v;
 }
 
@@ -918,13 +920,18 @@ typedef float zimg_t;
 __device__ __forceinline__ float zimg_ld(const zimg_t *__restrict__ z, int i) { return ld_u32(z, i); }
 __device__ __forceinline__ zimg_t zimg_pack(bool keep, unsigned, float zsf) { return keep ? zsf : NAN; }
 #endif
-__device__ __forceinline__ F3 org_point(const OrgGeom &g, int u, int v, float zsf)
+// (suf, svf): the SCENE pixel as floats, (float)(g.sx0 + u) and (float)(g.sy0 + v)
+__device__ __forceinline__ F3 org_point_f(const OrgGeom &g, float suf, float svf, float zsf)
 {
   F3 p;
-  p.x = ((((float)(g.sx0 + u) - g.cx) * g.inv_fx) * zsf) * 1000;
-  p.y = ((((float)(g.sy0 + v) - g.cy) * g.inv_fy) * zsf) * 1000;
+  p.x = (((suf - g.cx) * g.inv_fx) * zsf) * 1000;
+  p.y = (((svf - g.cy) * g.inv_fy) * zsf) * 1000;
   p.z = zsf * 1000;
   return p;
+}
+__device__ __forceinline__ F3 org_point(const OrgGeom &g, int u, int v, float zsf)
+{
+  return org_point_f(g, (float)(g.sx0 + u), (float)(g.sy0 + v), zsf);
 }
 // whole-wave minimum / maximum of an int by DPP (row_shr 1, 2, 4, 8, row_bcast 15 / 31), returned as a wave-uniform value
 #define FL_DPP_RED(OP, IDENT)                                                                                 \
@@ -1505,6 +1512,19 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 #endif
 #define ICP_PIPE_NP 6
 
+  // Slot s = lane + 64 p of a staged W-wide rectangle -> its row and column and the crop position base + row * cw + col, in
+  // float32: every value is an integer below 2^24 (small_crop), so each product, fma and sum is exact, at full rate, where the
+  // integer forms cost two quarter-rate multiplies per slot (v_mul_lo_u32, v_mad_u64_u32).
+  struct SlotPos { float row, col, pos; };
+  const float cwf = (float)og.cw;
+  const bool small_crop = (long long)og.cw * og.ch + NN_OVERRUN < (1 << 24);
+  auto slot_pos = [&](float slotf, float Wf, float invW, float basef) {
+    SlotPos r;
+    r.row = __builtin_truncf((slotf + 0.5f) * invW);
+    r.col = __builtin_fmaf(-r.row, Wf, slotf);
+    r.pos = __builtin_fmaf(r.row, cwf, r.col + basef);
+    return r;
+  };
   struct Prep {
     int i;                                   // the lane's query (model index) and point
     float qx, qy, qz;
@@ -1520,6 +1540,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     const float *rimg = (const float *)sref;
     const zimg_t *zimg = (const zimg_t *)(wsb + L.zimg);
     const int last_s = n_model - 1, last_pt = og.cw * og.ch + NN_OVERRUN - 1;
+    const float lanef = (float)lane;
     const float cul = uniform_f(og.offu + 0.01f), cuh = uniform_f(og.offu - 0.01f), cvl = uniform_f(og.offv + 0.01f), cvh = uniform_f(og.offv - 0.01f);
     constexpr int stride = NW * 64;
     // windows, union and staging loads of the step whose queries start at sb
@@ -1545,16 +1566,15 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const int W = P.any ? U1 - U0 + 1 : 1, H = P.any ? V1 - V0 + 1 : 1, area = W * H;
       const int npneed = (area + 3 + 63) >> 6;
       P.npass = npneed <= 2 ? 2 : npneed;
-      P.staged = P.any && npneed <= ICP_PIPE_NP;
+      P.staged = P.any && npneed <= ICP_PIPE_NP && small_crop;
       P.U0 = P.any ? U0 : 0; P.V0 = P.any ? V0 : 0; P.W = W;
-      const float invW = uniform_f(__builtin_amdgcn_rcpf((float)W));
-      const int base = (int)__umul24((unsigned)P.V0, (unsigned)og.cw) + P.U0;
+      const float Wf = (float)W, invW = uniform_f(__builtin_amdgcn_rcpf(Wf));
+      const float basef = (float)((int)__umul24((unsigned)P.V0, (unsigned)og.cw) + P.U0);
       const int np_eff = P.staged ? P.npass : 0;               // passes that hold the rectangle; the others read the guard
 #pragma unroll
       for (int p = 0; p < ICP_PIPE_NP; ++p) {
-        const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
-        const int pos = min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
-        P.z[p] = zimg_ld(zimg, p < np_eff ? pos : last_pt);
+        const SlotPos sp = slot_pos(lanef + (float)(64 * p), Wf, invW, basef);
+        P.z[p] = zimg_ld(zimg, p < np_eff ? min((int)sp.pos, last_pt) : last_pt);
       }
     };
     // the step itself: rebuild and stage its rectangle, scan, unpack
@@ -1567,14 +1587,14 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const int wl = u_hi - u_lo, hl = v_hi - v_lo;
       unsigned long long best = NN_KEY_NONE;
       if (P.staged) {
-        const float invW = uniform_f(__builtin_amdgcn_rcpf((float)W));
-        const int base = (int)__umul24((unsigned)V0, (unsigned)og.cw) + U0;
+        const float Wf = (float)W, invW = uniform_f(__builtin_amdgcn_rcpf(Wf));
+        const float basef = (float)((int)__umul24((unsigned)V0, (unsigned)og.cw) + U0);
+        const float suf = (float)(og.sx0 + U0), svf = (float)(og.sy0 + V0);   // scene pixel of the rectangle's corner
         auto put = [&](int p) {
-          const int row = (int)(((float)(lane + 64 * p) + 0.5f) * invW), col = lane + 64 * p - row * W;
-          const int pos = min((int)__umul24((unsigned)row, (unsigned)og.cw) + col + base, last_pt);
+          const SlotPos sp = slot_pos(lanef + (float)(64 * p), Wf, invW, basef);
           const float zf = P.z[p];
-          const F3 pt = org_point(og, U0 + col, V0 + row, zf);
-          stage[lane + 64 * p] = nn_point(pt.x, pt.y, pt.z, zf != zf ? NN_IDX_NONE : pos);
+          const F3 pt = org_point_f(og, suf + sp.col, svf + sp.row, zf);
+          stage[lane + 64 * p] = nn_point(pt.x, pt.y, pt.z, zf != zf ? NN_IDX_NONE : min((int)sp.pos, last_pt));
         };
         put(0);
         put(1);
@@ -1584,10 +1604,10 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float4 *row0 = stage + (v_lo - V0) * W + (u_lo - U0);
+        const float4 *row0 = stage + __mul24(v_lo - V0, W) + (u_lo - U0);
         if (nbw == 1) {
           for (int dv = 0; dv < maxh; ++dv) {
-            const float4 *bp = row0 + min(dv, hl) * W;
+            const float4 *bp = row0 + __mul24(min(dv, hl), W);
             float4 cur[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) cur[e] = bp[e];
@@ -1597,7 +1617,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         } else {
           const int wlc = max(wl - 3, 0);
           for (int dv = 0; dv < maxh; ++dv) {
-            const float4 *rowp = row0 + min(dv, hl) * W;
+            const float4 *rowp = row0 + __mul24(min(dv, hl), W);
             for (int du = 0; du < 4 * nbw; du += 4) {
               const float4 *bp = rowp + min(du, wlc);
               float4 cur[4];
