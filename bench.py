@@ -562,7 +562,7 @@ def pmc_traffic(args, bank, kernel):
             detail["valu_pipe_busy"] = round(issue / 2.0, 3)
             detail["valu_note"] = ("valu_issue_per_simd_quadcycle: vector instructions issued per SIMD and quad-cycle (one wave alone can "
                                    "reach 1.0, a SIMD-32 with two or more waves issuing 2.0); valu_pipe_busy = that / 2: the vector "
-                                   "ALUs are about a third busy -- not the bound (5 % fewer vector instructions measured the same); "
+                                   "ALUs are about half busy and the waves wait half of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES) -- no unit is saturated; "
                                    "DESIGN.md section 4, profiles/README.md")
         return (2.0 * kd["FETCH_SIZE"] + kd["WRITE_SIZE"]) * 1024.0, detail
     except Exception:

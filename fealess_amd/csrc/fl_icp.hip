@@ -1840,6 +1840,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       };
       constexpr bool ZIMG = FL_ICP_ZIMG && ORG && NW < 8;
       const zimg_t *zimg = (const zimg_t *)(wsb + L.zimg);
+      const float inv_cw = uniform_f(1.0f / (float)max(og.cw, 1));
       auto row_load = [&](Row &w, int t) {                 // issue only: nothing here reads what it loads
         const int i = t * TQ + slot;
         w.in = i < rows;
@@ -1859,8 +1860,19 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         float (*tile)[SH::TS] = S.prod[t & 1];
         F3 rp = w.r;
         if (ZIMG) {                                        // the partner's point from its pixel and depth factor (org_point)
-          const int jj = max(w.j, 0), vv = jj / og.cw;
-          rp = org_point(og, jj - vv * og.cw, vv, w.r.x);
+          // its crop row by a float reciprocal and one correction step instead of an integer division (three quarter-rate
+          // multiplies): exact for every pixel index (the estimate is off by at most one below 2^24 pixels; beyond: divide)
+          const int jj = max(w.j, 0);
+          int vv, uu;
+          if (small_crop) {
+            vv = (int)(((float)jj + 0.5f) * inv_cw);
+            uu = jj - __mul24(vv, og.cw);
+            if (uu < 0) { --vv; uu += og.cw; } else if (uu >= og.cw) { ++vv; uu -= og.cw; }
+          } else {
+            vv = jj / og.cw;
+            uu = jj - vv * og.cw;
+          }
+          rp = org_point(og, uu, vv, w.r.x);
         }
         const float mm[3] = {have ? w.m.x : 0.0f, have ? w.m.y : 0.0f, have ? w.m.z : 0.0f};
         const float rr[3] = {have ? rp.x : 0.0f, have ? rp.y : 0.0f, have ? rp.z : 0.0f};
