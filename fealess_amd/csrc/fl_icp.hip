@@ -965,12 +965,88 @@ __device__ __forceinline__ void wave_max_multi(int (&v)[N])
   for (int k = 0; k < N; ++k) v[k] = __builtin_amdgcn_readlane(v[k], 63);
 }
 
+// Six whole-wave maxima with gfx950's lane-swap instructions: v_permlane32_swap exchanges the upper half of one register with
+// the lower half of another, so ONE maximum of the swapped pair folds the two halves of BOTH values (value A's partials now live
+// in lanes 0-31, value B's in 32-63); v_permlane16_swap does the same for 16-lane rows.  Four values folded into the four rows
+// of one register and two into the halves of another need 4 + 5 DPP steps in all where six separate reductions need 36:
+// 19 vector instructions instead of 36 (+ their wait states) per search step.
+__device__ __forceinline__ void wave_max6(int (&v)[6])
+{
+  auto fold32 = [](int a, int b) {                         // lanes 0-31: max over a's halves, lanes 32-63: over b's
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    return max((int)r[0], (int)r[1]);
+  };
+  const int m01 = fold32(v[0], v[1]), m23 = fold32(v[2], v[3]);
+  int m45 = fold32(v[4], v[5]);
+  const auto q = __builtin_amdgcn_permlane16_swap((unsigned)m01, (unsigned)m23, false, false);
+  int n = max((int)q[0], (int)q[1]);                        // rows 0..3: v[0], v[2], v[1], v[3] (16 partials each)
+#define FL_DPP_STEP2(CTRL)                                                                                             \
+  n = max(n, __builtin_amdgcn_update_dpp((int)0x80000000, n, CTRL, 0xF, 0xF, false));                                  \
+  m45 = max(m45, __builtin_amdgcn_update_dpp((int)0x80000000, m45, CTRL, 0xF, 0xF, false));
+  FL_DPP_STEP2(0x111)
+  FL_DPP_STEP2(0x112)
+  FL_DPP_STEP2(0x114)
+  FL_DPP_STEP2(0x118)
+#undef FL_DPP_STEP2
+  m45 = max(m45, __builtin_amdgcn_update_dpp((int)0x80000000, m45, 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
+  v[0] = __builtin_amdgcn_readlane(n, 15);
+  v[2] = __builtin_amdgcn_readlane(n, 31);
+  v[1] = __builtin_amdgcn_readlane(n, 47);
+  v[3] = __builtin_amdgcn_readlane(n, 63);
+  v[4] = __builtin_amdgcn_readlane(m45, 31);
+  v[5] = __builtin_amdgcn_readlane(m45, 63);
+}
+// dev / tests: both reductions on one wavefront of inputs (tests/test_gpu_icp.py checks them against each other and numpy)
+__global__ void k_dev_wave_max6(const int *in, int *out)
+{
+  int a[6], b[6];
+  for (int k = 0; k < 6; ++k) a[k] = b[k] = in[k * 64 + threadIdx.x];
+  wave_max6(a);
+  wave_max_multi(b);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 6; ++k) { out[k] = a[k]; out[6 + k] = b[k]; }
+}
+
+// host entry for the test: 6 x 64 ints in, 6 (wave_max6) + 6 (wave_max_multi) out; plain HIP calls on the null stream
+extern "C" int fl_dev_wave_max6(const int *in_host, int *out_host)
+{
+  int *d_in = nullptr, *d_out = nullptr;
+  if (hipMalloc(&d_in, 6 * 64 * sizeof(int)) != hipSuccess || hipMalloc(&d_out, 12 * sizeof(int)) != hipSuccess) { hipFree(d_in); return FL_ERR_HIP; }
+  bool ok = hipMemcpy(d_in, in_host, 6 * 64 * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_dev_wave_max6, dim3(1), dim3(64), 0, 0, d_in, d_out);
+    ok = hipGetLastError() == hipSuccess && hipMemcpy(out_host, d_out, 12 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  hipFree(d_in);
+  hipFree(d_out);
+  return ok ? FL_OK : FL_ERR_HIP;
+}
 
 // The crop pixels whose points can lie within distance r of q: a point (X, Y, Z) of pixel (su, sv) satisfies
 // su - cx = X fx / Z up to float rounding (it was generated as X = ((su - cx) / fx) Z), and |X - qx|, |Z - qz| <= r.
 // The 0.01-pixel slop is an order of magnitude above that rounding (5e-7 relative on |su - cx| <= 2000 pixels).  An empty window has u_lo > u_hi.
 // (the constants folded -- cul / cuh = offu +- slop, cvl / cvh = offv +- slop, wave-uniform -- and the clamping left to the
 // saturating float -> int conversion; returns whether the window holds a pixel)
+// Branch-free form of org_window2 for the pipelined step: every lane computes the projection (a lane whose radius is not finite
+// or reaches Z <= 1 computes garbage and selects the whole crop, a lane that is not queryable selects nothing), so that a step
+// has no exec-mask regions in front of its reductions.  Same windows.
+__device__ __forceinline__ bool org_window2_flat(const OrgGeom &g, float cul, float cuh, float cvl, float cvh, float qx, float qy, float qz, float r,
+                                                 bool queryable, int &u_lo, int &u_hi, int &v_lo, int &v_hi)
+{
+  const float zlo = qz - r, zhi = qz + r;
+  const bool narrow = isfinite(r) && zlo > 1.0f;         // otherwise the whole crop (valid points have 0 < Z <= 900)
+  const float ilo = __builtin_amdgcn_rcpf(zlo), ihi = __builtin_amdgcn_rcpf(zhi);
+  const float xlo = qx - r, xhi = qx + r, ylo = qy - r, yhi = qy + r;
+  const int iul = cvt_i32_sat(ceilf((xlo * (xlo < 0.f ? ilo : ihi)) * g.fx - cul));
+  const int iuh = cvt_i32_sat(floorf((xhi * (xhi > 0.f ? ilo : ihi)) * g.fx - cuh));
+  const int ivl = cvt_i32_sat(ceilf((ylo * (ylo < 0.f ? ilo : ihi)) * g.fy - cvl));
+  const int ivh = cvt_i32_sat(floorf((yhi * (yhi > 0.f ? ilo : ihi)) * g.fy - cvh));
+  u_lo = narrow ? max(iul, 0) : 0;
+  u_hi = narrow ? min(iuh, g.cw - 1) : g.cw - 1;
+  v_lo = narrow ? max(ivl, 0) : 0;
+  v_hi = narrow ? min(ivh, g.ch - 1) : g.ch - 1;
+  return queryable & (u_lo <= u_hi) & (v_lo <= v_hi);
+}
 __device__ __forceinline__ bool org_window2(const OrgGeom &g, float cul, float cuh, float cvl, float cvh, float qx, float qy, float qz, float r,
                                             int &u_lo, int &u_hi, int &v_lo, int &v_hi)
 {
@@ -1548,21 +1624,20 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       P.i = i; P.qx = q.x; P.qy = q.y; P.qz = q.z;
       P.active = sb + lane < n_model;
       P.queryable = P.active && r_lim >= 0.f && isfinite(q.x) && isfinite(q.y) && isfinite(q.z);
-      int u_lo = 1, u_hi = 0, v_lo = 1, v_hi = 0;
-      bool some = false;
-      if (P.queryable) some = org_window2(og, cul, cuh, cvl, cvh, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_lim)), u_lo, u_hi, v_lo, v_hi);
+      int u_lo, u_hi, v_lo, v_hi;
+      const bool some = org_window2_flat(og, cul, cuh, cvl, cvh, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_lim)), P.queryable,
+                                         u_lo, u_hi, v_lo, v_hi);
       const int big = 0x3fffffff;
-      int red[5] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0};
-      wave_max_multi(red);
+      // union rectangle, tallest and widest lane window (a lane without a window: one pixel of the union, width 0)
+      int red[6] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0,
+                    some ? u_hi - u_lo : 0};
+      wave_max6(red);
       const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3];
       P.maxh = red[4];
       P.any = U1 >= U0;
       if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }
       P.u_lo = u_lo; P.u_hi = u_hi; P.v_lo = v_lo; P.v_hi = v_hi;
-      const int wl = u_hi - u_lo;
-      int nbw = 1;
-      if (P.any && __ballot(wl > 3) != 0ull) nbw = __ballot(wl > 7) == 0ull ? 2 : (wave_max_i(wl) >> 2) + 1;
-      P.nbw = nbw;
+      P.nbw = P.any ? (red[5] >> 2) + 1 : 1;                     // batches of four positions per row: 1 up to width 3, 2 up to 7, ...
       const int W = P.any ? U1 - U0 + 1 : 1, H = P.any ? V1 - V0 + 1 : 1, area = W * H;
       const int npneed = (area + 3 + 63) >> 6;
       P.npass = npneed <= 2 ? 2 : npneed;

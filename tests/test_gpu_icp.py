@@ -37,6 +37,33 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def test_wave_reductions_of_the_search_step_agree(ctx):
+    """The six whole-wave maxima a search step takes (union rectangle, tallest and widest lane window) are folded through
+    gfx950's lane-swap instructions (wave_max6, fl_icp.hip); the plain DPP reduction (wave_max_multi) and numpy must agree
+    on every value, including ties, extremes and values confined to one lane."""
+    import ctypes as C
+    lib = L.load()
+    lib.fl_dev_wave_max6.restype = C.c_int
+    lib.fl_dev_wave_max6.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(7)
+    cases = [rng.integers(-2 ** 31, 2 ** 31 - 1, size=(6, 64), dtype=np.int64).astype(np.int32) for _ in range(20)]
+    cases += [rng.integers(-40, 700, size=(6, 64)).astype(np.int32) for _ in range(20)]
+    for lane in (0, 15, 16, 31, 32, 47, 48, 63):             # the maximum of value k sits in one lane only
+        a = np.full((6, 64), -0x3fffffff, np.int32)
+        a[:, lane] = np.arange(6) * 100 + lane
+        cases.append(a)
+    a = np.arange(6 * 64, dtype=np.int32).reshape(6, 64) * np.array([1, -1, 3, -3, 7, -7], np.int32)[:, None]
+    cases.append(a)
+    for a in cases:
+        a = np.ascontiguousarray(a, np.int32)
+        out = np.zeros(12, np.int32)
+        rc = lib.fl_dev_wave_max6(a.ctypes.data_as(C.POINTER(C.c_int)), out.ctypes.data_as(C.POINTER(C.c_int)))
+        assert rc == 0
+        want = a.max(axis=1)
+        assert np.array_equal(out[:6], want), (out[:6], want)
+        assert np.array_equal(out[6:], want), (out[6:], want)
+
+
 @pytest.mark.parametrize("w,h,K", [(640, 480, (608.0, 608.0, 320.0, 240.0)), (1280, 720, (915.3, 917.1, 641.2, 358.7)),
                                    (33, 17, (50.0, 60.0, 16.0, 8.0))])
 def test_depth_to_3d_bit_exact(ctx, oracle, w, h, K):
