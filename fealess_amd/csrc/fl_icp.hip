@@ -1011,14 +1011,14 @@ __global__ void k_dev_wave_max6(const int *in, int *out)
 extern "C" int fl_dev_wave_max6(const int *in_host, int *out_host)
 {
   int *d_in = nullptr, *d_out = nullptr;
-  if (hipMalloc(&d_in, 6 * 64 * sizeof(int)) != hipSuccess || hipMalloc(&d_out, 12 * sizeof(int)) != hipSuccess) { hipFree(d_in); return FL_ERR_HIP; }
+  if (hipMalloc(&d_in, 6 * 64 * sizeof(int)) != hipSuccess || hipMalloc(&d_out, 12 * sizeof(int)) != hipSuccess) { (void)hipFree(d_in); return FL_ERR_HIP; }
   bool ok = hipMemcpy(d_in, in_host, 6 * 64 * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
   if (ok) {
     hipLaunchKernelGGL(k_dev_wave_max6, dim3(1), dim3(64), 0, 0, d_in, d_out);
     ok = hipGetLastError() == hipSuccess && hipMemcpy(out_host, d_out, 12 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
   }
-  hipFree(d_in);
-  hipFree(d_out);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
   return ok ? FL_OK : FL_ERR_HIP;
 }
 
@@ -1627,22 +1627,23 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       int u_lo, u_hi, v_lo, v_hi;
       const bool some = org_window2_flat(og, cul, cuh, cvl, cvh, q.x, q.y, q.z, nn_radius(q.x, q.y, q.z, fminf(b, r_lim)), P.queryable,
                                          u_lo, u_hi, v_lo, v_hi);
-      const int big = 0x3fffffff;
-      // union rectangle, tallest and widest lane window (a lane without a window: one pixel of the union, width 0)
-      int red[6] = {some ? -u_lo : -big, some ? u_hi : -1, some ? -v_lo : -big, some ? v_hi : -1, some ? v_hi - v_lo + 1 : 0,
+      // union rectangle, tallest and widest lane window (a lane without a window: one pixel of the union, width 0).  A lane
+      // without a window contributes the crop's far corners -- neutral among real windows, and a step in which NO lane has one
+      // still gets a pixel of the crop as its "union" without a single wave-uniform select (each costs four scalar instructions)
+      int red[6] = {some ? -u_lo : 1 - og.cw, some ? u_hi : 0, some ? -v_lo : 1 - og.ch, some ? v_hi : 0, some ? v_hi - v_lo + 1 : 0,
                     some ? u_hi - u_lo : 0};
       wave_max6(red);
       const int U0 = -red[0], U1 = red[1], V0 = -red[2], V1 = red[3];
       P.maxh = red[4];
-      P.any = U1 >= U0;
+      P.any = red[4] > 0;                                        // some lane has a window
       if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }
       P.u_lo = u_lo; P.u_hi = u_hi; P.v_lo = v_lo; P.v_hi = v_hi;
-      P.nbw = P.any ? (red[5] >> 2) + 1 : 1;                     // batches of four positions per row: 1 up to width 3, 2 up to 7, ...
-      const int W = P.any ? U1 - U0 + 1 : 1, H = P.any ? V1 - V0 + 1 : 1, area = W * H;
+      P.nbw = (red[5] >> 2) + 1;                                 // batches of four positions per row: 1 up to width 3, 2 up to 7, ...
+      const int W = max(U1 - U0 + 1, 1), H = max(V1 - V0 + 1, 1), area = W * H;
       const int npneed = (area + 3 + 63) >> 6;
       P.npass = npneed <= 2 ? 2 : npneed;
       P.staged = P.any && npneed <= ICP_PIPE_NP && small_crop;
-      P.U0 = P.any ? U0 : 0; P.V0 = P.any ? V0 : 0; P.W = W;
+      P.U0 = U0; P.V0 = V0; P.W = W;
       const float Wf = (float)W, invW = uniform_f(__builtin_amdgcn_rcpf(Wf));
       const float basef = (float)((int)__umul24((unsigned)P.V0, (unsigned)og.cw) + P.U0);
       const int np_eff = P.staged ? P.npass : 0;               // passes that hold the rectangle; the others read the guard
