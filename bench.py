@@ -483,6 +483,13 @@ def main():
               (span, life.mean(), life.min(), life.max(), min(len(res), 1280), life.sum() / (span * min(len(res), 1280)), t0.max() - t0.min(),
                t1.min() - t0.min(), int((t1 > t0.min() + 0.9 * span).sum())), file=sys.stderr)
         hs = np.array([[0.0] * 5 + list(r.pose)[5:] + list(r.det.R_final) + list(r.det.T_final) for r in res]).sum(0)
+        if hs[5:11].sum() > 0:                               # the pipelined search step's own bins (org_search_pipe)
+            nst = max(hs[5:8].sum(), 1)
+            print("icp pipelined search step: scanned positions per lane and step %.1f, of which inside the lane's own window %.1f; "
+                  "batches per row 1 / 2 / 3+: %s %%; staged passes 2 / 3 / 4+: %s %%; tallest lane window 1..6+ rows: %s %%" %
+                  (st[1] / max(st[0], 1), st[4] / 64.0 / max(st[0], 1), np.round(100 * hs[5:8] / nst, 1).tolist(),
+                   np.round(100 * hs[8:11] / nst, 1).tolist(), np.round(100 * hs[16:22] / nst, 1).tolist()), file=sys.stderr)
+            print("icp pipelined search step: widest lane window 1 / 2 / 3 / 4 / 5+ pixels: %s %%" % np.round(100 * hs[11:16] / nst, 1).tolist(), file=sys.stderr)
         stt = hs[11:16].copy() / len(res) / 4e6              # per wave (4 waves per workgroup), M cycles
         hs[11:16] = 0
         a2 = hs[22:25].copy() * 16 / len(res) / 1e6

@@ -1607,6 +1607,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     bool active, queryable;
     int u_lo, u_hi, v_lo, v_hi;              // its window (one pixel of the union if it has none)
     int U0, V0, W, maxh, nbw, npass;         // wave-uniform: union rectangle, tallest window, batches per row, passes
+#ifdef FL_ICP_PHASES
+    int wlmax;
+#endif
     bool any, staged;
     float z[ICP_PIPE_NP];                    // depth factors of the staged slots lane + 64 p (in flight until finish)
   };
@@ -1639,6 +1642,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }
       P.u_lo = u_lo; P.u_hi = u_hi; P.v_lo = v_lo; P.v_hi = v_hi;
       P.nbw = (red[5] >> 2) + 1;                                 // batches of four positions per row: 1 up to width 3, 2 up to 7, ...
+#ifdef FL_ICP_PHASES
+      P.wlmax = red[5];
+#endif
       const int W = max(U1 - U0 + 1, 1), H = max(V1 - V0 + 1, 1), area = W * H;
       const int npneed = (area + 3 + 63) >> 6;
       P.npass = npneed <= 2 ? 2 : npneed;
@@ -1661,6 +1667,23 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       const float qx = P.qx, qy = P.qy, qz = P.qz;
       const int u_lo = P.u_lo, u_hi = P.u_hi, v_lo = P.v_lo, v_hi = P.v_hi, W = P.W, U0 = P.U0, V0 = P.V0, maxh = P.maxh, nbw = P.nbw;
       const int wl = u_hi - u_lo, hl = v_hi - v_lo;
+#ifdef FL_ICP_PHASES
+      {                                                    // dev: steps, scanned / staged positions, what the lanes' own windows hold
+        int own = P.queryable ? (wl + 1) * (hl + 1) : 0;
+        for (int sft = 32; sft >= 1; sft >>= 1) own += __shfl_xor(own, sft, 64);
+        if (lane == 0) {
+          atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
+          atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(4 * nbw * maxh));
+          atomicAdd((unsigned long long *)&S.tacc[10], P.staged ? 0ull : 1ull);
+          atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)(P.staged ? P.npass * 64 : 0));
+          atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)own);     // summed over the 64 lanes
+          atomicAdd(&S.hist[16 + min(maxh, 6) - 1], 1u);   // (bins 22..24 and 26..28 carry the chain phases' stamps)
+          atomicAdd(&S.hist[5 + min(nbw, 3) - 1], 1u);     // bins 5..7: 1, 2, 3+ batches per row
+          atomicAdd(&S.hist[8 + min(P.npass, 4) - 2], 1u); // bins 8..10: 2, 3, 4+ staged passes
+          atomicAdd(&S.stime[min(P.wlmax, 4)], 1ull);      // widest lane window of the step: 1, 2, 3, 4, 5+ pixels
+        }
+      }
+#endif
       unsigned long long best = NN_KEY_NONE;
       if (P.staged) {
         const float Wf = (float)W, invW = uniform_f(__builtin_amdgcn_rcpf(Wf));
