@@ -62,6 +62,17 @@ __global__ __launch_bounds__(256) void k_build_lm_generic(const uint8_t *__restr
 // 4 VALU instructions instead of the ~35 of an integer division by a run-time divisor.
 __device__ __forceinline__ int div_small(int i, float inv_d) { return (int)(((float)i + 0.5f) * inv_d); }
 
+// OR of the T four-byte windows at byte offsets 0 .. T - 1 (T <= 8) of the 12 bytes s0 s1 s2: four pixels of the horizontal
+// spread.  One v_alignbyte_b32 extracts a window (full rate); the 64-bit shifts this replaces compiled to a quarter-rate
+// 64-bit multiply-add per offset.
+__device__ __forceinline__ uint32_t or_windows(uint32_t s0, uint32_t s1, uint32_t s2, int T)
+{
+  uint32_t acc = s0;
+  for (int c = 1; c < T; ++c)
+    acc |= c < 4 ? __builtin_amdgcn_alignbyte(s1, s0, (unsigned)c) : __builtin_amdgcn_alignbyte(s2, s1, (unsigned)(c - 4));
+  return acc;
+}
+
 __global__ __launch_bounds__(256) void k_build_lm(const uint8_t *__restrict__ quant, size_t quant_stride,
                                                   uint8_t *__restrict__ lm, size_t lm_stride, int w, int h, int T,
                                                   int W, int H, int WH, uint32_t stride, int RS)
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(256) void k_build_lm(const uint8_t *__restrict__ qu
   const int ws4 = ws >> 2, w4 = w >> 2;
   const float inv_ws4 = 1.0f / (float)ws4, inv_w4 = 1.0f / (float)w4;
   for (int i = tid; i < rows_in * ws4; i += 256) {
-    const int r = div_small(i, inv_ws4), c4 = i - r * ws4;
+    const int r = div_small(i, inv_ws4), c4 = i - __mul24(r, ws4);
     const int y = y0 + r;
     uint32_t v = 0;
     if (y < h && c4 < w4) v = *(const uint32_t *)(q + (size_t)y * w + 4 * c4);
@@ -98,30 +109,29 @@ __global__ __launch_bounds__(256) void k_build_lm(const uint8_t *__restrict__ qu
   __syncthreads();
   // horizontal OR over T columns, 4 pixels per thread
   for (int i = tid; i < rows_in * w4; i += 256) {
-    const int r = div_small(i, inv_w4), c4 = i - r * w4;
-    const uint32_t *src = (const uint32_t *)(A + (size_t)r * ws) + c4;
-    const unsigned long long lo = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
-    const unsigned long long hi = (unsigned long long)src[2] | ((unsigned long long)src[3] << 32);
-    unsigned long long acc = lo;
-    for (int c = 1; c < T; ++c) acc |= (lo >> (8 * c)) | (hi << (64 - 8 * c));   // T <= 8: c <= 7
-    ((uint32_t *)(B + (size_t)r * ws))[c4] = (uint32_t)acc;
+    const int r = div_small(i, inv_w4), c4 = i - __mul24(r, w4);
+    const int o = __mul24(r, ws4) + c4;                  // dword offset in the padded LDS images (32-bit: a (size_t) row offset
+    const uint32_t *src = (const uint32_t *)A + o;       // costs a quarter-rate 64-bit multiply-add per row)
+    ((uint32_t *)B)[o] = or_windows(src[0], src[1], src[2], T);                                    // T <= 8: offsets <= 7
   }
   __syncthreads();
   // vertical OR over T rows -> spread image of the strip, back into A
   for (int i = tid; i < RS * w4; i += 256) {
-    const int r = div_small(i, inv_w4), c4 = i - r * w4;
+    const int r = div_small(i, inv_w4), c4 = i - __mul24(r, w4);
+    const int o = __mul24(r, ws4) + c4;
+    const uint32_t *bp = (const uint32_t *)B + o;
     uint32_t acc = 0;
-    for (int rr = 0; rr < T; ++rr) acc |= ((const uint32_t *)(B + (size_t)(r + rr) * ws))[c4];
-    ((uint32_t *)(A + (size_t)r * ws))[c4] = acc;
+    for (int rr = 0; rr < T; ++rr, bp += ws4) acc |= *bp;
+    ((uint32_t *)A)[o] = acc;
   }
   __syncthreads();
   const int yt0 = y0 / T, nyt = min(RS / T, H - yt0), W4 = W >> 2;
   const int items = T * T * nyt * W4;
   const float inv_W4 = 1.0f / (float)W4, inv_nyt = 1.0f / (float)max(nyt, 1), inv_T = 1.0f / (float)T;
   for (int it = tid; it < items; it += 256) {
-    const int t2 = div_small(it, inv_W4), xt4 = it - t2 * W4;
-    const int gi = div_small(t2, inv_nyt), yt = t2 - gi * nyt;
-    const int gy = div_small(gi, inv_T), gx = gi - gy * T;
+    const int t2 = div_small(it, inv_W4), xt4 = it - __mul24(t2, W4);
+    const int gi = div_small(t2, inv_nyt), yt = t2 - __mul24(gi, nyt);
+    const int gy = div_small(gi, inv_T), gx = gi - __mul24(gy, T);
     const uint8_t *srow = A + (size_t)(yt * T + gy) * ws + gx + (size_t)xt4 * 4 * T;
     const unsigned long long r0 = tab[srow[0]], r1 = tab[srow[T]], r2 = tab[srow[2 * T]], r3 = tab[srow[3 * T]];
     uint8_t *dst = out + (size_t)gi * WH + (size_t)(yt0 + yt) * W + 4 * xt4;
@@ -172,28 +182,26 @@ __global__ __launch_bounds__(256) void k_spread(const uint8_t *__restrict__ quan
   const int n_in = min(ws4, lo4 + n_out + 3) - lo4;        // the horizontal OR of dword c reads dwords c .. c + 3
   const float inv_in = 1.0f / (float)n_in, inv_out = 1.0f / (float)n_out;
   for (int i = tid; i < rows_in * n_in; i += 256) {
-    const int r = div_small(i, inv_in), c4 = lo4 + (i - r * n_in);
+    const int r = div_small(i, inv_in), c4 = lo4 + (i - __mul24(r, n_in));
     const int y = y0 + r;
     uint32_t v = 0;
     if (y < h && c4 < w4) v = *(const uint32_t *)(q + (size_t)y * w + 4 * c4);
-    ((uint32_t *)A)[r * ws4 + c4] = v;
+    ((uint32_t *)A)[__mul24(r, ws4) + c4] = v;
   }
   __syncthreads();
   for (int i = tid; i < rows_in * n_out; i += 256) {
-    const int r = div_small(i, inv_out), c4 = lo4 + (i - r * n_out);
-    const uint32_t *src = (const uint32_t *)(A + (size_t)r * ws) + c4;
-    const unsigned long long lo = (unsigned long long)src[0] | ((unsigned long long)src[1] << 32);
-    const unsigned long long hi = (unsigned long long)src[2] | ((unsigned long long)src[3] << 32);
-    unsigned long long acc = lo;
-    for (int c = 1; c < T; ++c) acc |= (lo >> (8 * c)) | (hi << (64 - 8 * c));
-    ((uint32_t *)(B + (size_t)r * ws))[c4] = (uint32_t)acc;
+    const int r = div_small(i, inv_out), c4 = lo4 + (i - __mul24(r, n_out));
+    const int o = __mul24(r, ws4) + c4;
+    const uint32_t *src = (const uint32_t *)A + o;
+    ((uint32_t *)B)[o] = or_windows(src[0], src[1], src[2], T);
   }
   __syncthreads();
   for (int i = tid; i < RS * n_out; i += 256) {
-    const int r = div_small(i, inv_out), c4 = lo4 + (i - r * n_out);
+    const int r = div_small(i, inv_out), c4 = lo4 + (i - __mul24(r, n_out));
     if (y0 + r >= h) continue;
+    const uint32_t *bp = (const uint32_t *)B + (__mul24(r, ws4) + c4);
     uint32_t acc = 0;
-    for (int rr = 0; rr < T; ++rr) acc |= ((const uint32_t *)(B + (size_t)(r + rr) * ws))[c4];
+    for (int rr = 0; rr < T; ++rr, bp += ws4) acc |= *bp;
     *(uint32_t *)(out + (size_t)(y0 + r) * w + 4 * c4) = acc;
   }
 }
