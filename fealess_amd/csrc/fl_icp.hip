@@ -1607,6 +1607,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
     bool active, queryable;
     int u_lo, u_hi, v_lo, v_hi;              // its window (one pixel of the union if it has none)
     int U0, V0, W, maxh, nbw, npass;         // wave-uniform: union rectangle, tallest window, batches per row, passes
+    bool w3;                                 // no lane window is wider than 3 pixels: batches of 3 positions
 #ifdef FL_ICP_PHASES
     int wlmax;
 #endif
@@ -1642,6 +1643,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       if (!some) { u_lo = u_hi = U0; v_lo = v_hi = V0; }
       P.u_lo = u_lo; P.u_hi = u_hi; P.v_lo = v_lo; P.v_hi = v_hi;
       P.nbw = (red[5] >> 2) + 1;                                 // batches of four positions per row: 1 up to width 3, 2 up to 7, ...
+      P.w3 = red[5] <= 2;
 #ifdef FL_ICP_PHASES
       P.wlmax = red[5];
 #endif
@@ -1704,7 +1706,16 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float4 *row0 = stage + __mul24(v_lo - V0, W) + (u_lo - U0);
-        if (nbw == 1) {
+        if (P.w3) {                                        // (nearly half of the steps: a quarter of their scan saved)
+          for (int dv = 0; dv < maxh; ++dv) {
+            const float4 *bp = row0 + __mul24(min(dv, hl), W);
+            float4 cur[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) cur[e] = bp[e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) NN_CONSIDER(cur[e])
+          }
+        } else if (nbw == 1) {
           for (int dv = 0; dv < maxh; ++dv) {
             const float4 *bp = row0 + __mul24(min(dv, hl), W);
             float4 cur[4];
