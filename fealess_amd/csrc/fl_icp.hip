@@ -1675,7 +1675,7 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
         for (int sft = 32; sft >= 1; sft >>= 1) own += __shfl_xor(own, sft, 64);
         if (lane == 0) {
           atomicAdd((unsigned long long *)&S.tacc[8], 1ull);
-          atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)(4 * nbw * maxh));
+          atomicAdd((unsigned long long *)&S.tacc[9], (unsigned long long)((P.w3 ? 3 : 4 * nbw) * maxh));
           atomicAdd((unsigned long long *)&S.tacc[10], P.staged ? 0ull : 1ull);
           atomicAdd((unsigned long long *)&S.tacc[11], (unsigned long long)(P.staged ? P.npass * 64 : 0));
           atomicAdd((unsigned long long *)&S.tacc[12], (unsigned long long)own);     // summed over the 64 lanes
