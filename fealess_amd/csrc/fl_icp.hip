@@ -113,6 +113,9 @@
                                   // against a larger staged rectangle; measured at 4096 frames, ICP ms per launch: 4 x 16 35.4, 8 x 8 33.9 / 33.8,
                                   // 16 x 4 33.6 / 33.6, 32 x 2 35.8
 #endif
+#ifndef FL_ICP_TILE_COLMAJOR
+#define FL_ICP_TILE_COLMAJOR 1    // the order of the pixels inside a search tile (build_tile_order)
+#endif
 #ifndef FL_ICP_BPD
 #define FL_ICP_BPD 1              // dist_mean phase: tiles of (mod, ref, bnd) loads a producer thread keeps in flight (1 or 2)
 #endif
@@ -2341,7 +2344,14 @@ __device__ __forceinline__ void build_tile_order(SH &S, const int *idximg, int c
     const int ty = (int)(((float)t + 0.5f) * inv_ntx);
     int tx = t - ty * ntx;
     if (ty & 1) tx = ntx - 1 - tx;
+#if FL_ICP_TILE_COLMAJOR
+    // column by column inside a tile, in the direction the tile row is walked: 64 consecutive entries of perm[] -- a search
+    // step -- then always cover ONE contiguous run of columns of the tile row (row by row, a step that starts in the middle of
+    // a tile takes its lower rows, the next tile and the upper rows of the one after: up to three tiles wide)
+    const int c = lane / TH, x = tx * TW + ((ty & 1) ? TW - 1 - c : c), y = ty * TH + (lane & (TH - 1));
+#else
     const int x = tx * TW + (lane & (TW - 1)), y = ty * TH + lane / TW;
+#endif
     int k = NN_IDX_NONE;
     if (x < cw && y < ch) k = idximg[y * cw + x];
     has = (unsigned)k < (unsigned)NN_IDX_NONE;
