@@ -1590,6 +1590,9 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
 #define FL_ICP_PIPE 1
 #endif
 #define ICP_PIPE_NP 6
+#ifndef FL_ICP_PIPE_COND
+#define FL_ICP_PIPE_COND 1
+#endif
 
   // Slot s = lane + 64 p of a staged W-wide rectangle -> its row and column and the crop position base + row * cw + col, in
   // float32: every value is an integer below 2^24 (small_crop), so each product, fma and sum is exact, at full rate, where the
@@ -1657,12 +1660,25 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
       P.U0 = U0; P.V0 = V0; P.W = W;
       const float Wf = (float)W, invW = uniform_f(__builtin_amdgcn_rcpf(Wf));
       const float basef = (float)((int)__umul24((unsigned)P.V0, (unsigned)og.cw) + P.U0);
+#if FL_ICP_PIPE_COND
+      // two passes always, the others in pairs where the rectangle needs them (wave-uniform: with the column-major tiles seven
+      // steps in ten need two)
+      auto ldz = [&](int p) {
+        const SlotPos sp = slot_pos(lanef + (float)(64 * p), Wf, invW, basef);
+        P.z[p] = zimg_ld(zimg, P.staged ? min((int)sp.pos, last_pt) : last_pt);
+      };
+      ldz(0);
+      ldz(1);
+      if (P.staged && P.npass > 2) { ldz(2); ldz(3); }
+      if (P.staged && P.npass > 4) { ldz(4); ldz(5); }
+#else
       const int np_eff = P.staged ? P.npass : 0;               // passes that hold the rectangle; the others read the guard
 #pragma unroll
       for (int p = 0; p < ICP_PIPE_NP; ++p) {
         const SlotPos sp = slot_pos(lanef + (float)(64 * p), Wf, invW, basef);
         P.z[p] = zimg_ld(zimg, p < np_eff ? min((int)sp.pos, last_pt) : last_pt);
       }
+#endif
     };
     // the step itself: rebuild and stage its rectangle, scan, unpack
     auto finish = [&](const Prep &P, int &j, float &d) {
