@@ -113,6 +113,9 @@
                                   // against a larger staged rectangle; measured at 4096 frames, ICP ms per launch: 4 x 16 35.4, 8 x 8 33.9 / 33.8,
                                   // 16 x 4 33.6 / 33.6, 32 x 2 35.8
 #endif
+#ifndef FL_ICP_BMACRO
+#define FL_ICP_BMACRO 4           // dist_mean phase, 256-thread parity kernel: tiles per barrier (l2dist_phase)
+#endif
 #ifndef FL_ICP_TILE_COLMAJOR
 #define FL_ICP_TILE_COLMAJOR 1    // the order of the pixels inside a search tile (build_tile_order)
 #endif
@@ -1134,6 +1137,19 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   double dsum[1] = {0.0};
   float acc = 0.0f;
   const int ntiles = (n + TQ - 1) / TQ;
+  // 256-thread parity kernel: the chain wave and the producers meet at a barrier every KB tiles, not every tile.  The chain is
+  // one lane adding one float per row; at a barrier per 192 rows it spent 2 - 3 of its ~11 cycles per row there and in the LDS
+  // round trip that opens each tile (phase stamps: 11.3 -> 9.5 cycles per row inside blocks of 4, 8.6 inside blocks of 8 -- but
+  // the chain starts a block after the producers and ends a block after them, which is why 4 beats 8 and 15; blocks graded
+  // 1, 1, 2, 2, 4, 4, 8 ... from both ends cost more in bookkeeping than they saved).  The terms of a block go to one of two
+  // buffers of KB tiles in the (idle) tiles of phase A2.
+  constexpr int KB = parity && !allprod && !SH::BSUM && SH::NW < 8 ? FL_ICP_BMACRO : 1;
+  static_assert(KB == 1 || sizeof(S.prod) >= (size_t)2 * KB * TQ * sizeof(float), "two blocks of KB tiles of terms fit the A2 tiles");
+  auto dbuf = [&](int t) -> float * {                    // where the terms of tile t go
+    if (KB == 1) return S.dtile[t & 1];
+    const int m = t / KB;
+    return (float *)&S.prod[0][0][0] + ((m & 1) * KB + (t - m * KB)) * TQ;
+  };
   // The phase is one memory round trip + one barrier per tile, so the next tile's (coalesced) loads are issued before this
   // tile is processed.  Two register sets trade roles by unrolling the tile loop twice -- never by moving registers, and
   // nothing computes with a loaded value in the iteration that issued its load: either makes the compiler drain the whole
@@ -1184,7 +1200,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
         ++counter;
       }
     }
-    if (parity) S.dtile[t & 1][slot] = term;              // non-inliers add an exact +0.0f
+    if (parity) dbuf(t)[slot] = term;                     // non-inliers add an exact +0.0f
     if (DEFER && i < n) dterm[i] = term;
   };
   auto tile_barrier = [&]() {
@@ -1193,12 +1209,16 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
       __builtin_amdgcn_s_barrier();
     }
   };
-  // tile t is complete in LDS: the chain wave adds it (every lane of the wave enters)
+  // tile t (block t of KB tiles) is complete in LDS: the chain wave adds it (every lane of the wave enters)
   auto chain_step = [&](int t) {
-    const float *col = S.dtile[t & 1];
-    const int rows = min(TQ, n - t * TQ);
+    const float *col = dbuf(t * KB);
+    const int rows = min(KB * TQ, n - t * KB * TQ);
     if (SH::BSUM) acc = chain_block_nonneg<SH::CHAIN_NBUF>(col, rows, acc);
     else if (clane == 0) acc = chain_tile<SH::CHAIN_NBUF>(col, rows, acc);
+  };
+  const int nblocks = (ntiles + KB - 1) / KB, nbar = KB == 1 ? ntiles : ntiles / KB;   // blocks of tiles; barriers inside the phase
+  auto block_barrier = [&](int t) {                       // behind tile t: the barrier that closes a block
+    if (KB == 1 || (t + 1) % KB == 0) tile_barrier();
   };
   const bool chain_wave = __builtin_amdgcn_readfirstlane(clane) >= 0;
   // producer loop: `before_barrier(t)` runs behind the rows of tile t (the chain wave's block sum of tile t - 1 when every wave
@@ -1211,18 +1231,18 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
       row_load(Z, t + 2);
       row_process(X, t);
       before_barrier(t);
-      PR_STAMP_BARRIER(28, 3);
+      block_barrier(t);
       if (t + 1 < ntiles) {
         row_load(X, t + 3);
         row_process(Y, t + 1);
         before_barrier(t + 1);
-        tile_barrier();
+        block_barrier(t + 1);
       }
       if (t + 2 < ntiles) {
         row_load(Y, t + 4);
         row_process(Z, t + 2);
         before_barrier(t + 2);
-        tile_barrier();
+        block_barrier(t + 2);
       }
     }
 #else
@@ -1232,12 +1252,12 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
       row_load(B, t + 1);
       row_process(A, t);
       before_barrier(t);
-      PR_STAMP_BARRIER(28, 2);
+      block_barrier(t);
       if (t + 1 < ntiles) {
         row_load(A, t + 2);
         row_process(B, t + 1);
         before_barrier(t + 1);
-        tile_barrier();
+        block_barrier(t + 1);
       }
     }
 #endif
@@ -1248,7 +1268,7 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   } else if (chain_wave) {
     // the chain wave's own loop (see the A2 phase): one barrier per tile like the producers' below
     CH_STAMP_BEGIN;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nbar; ++t) {
       if (t > 0) chain_step(t - 1);
       CH_STAMP(c_add);
       tile_barrier();
@@ -1258,10 +1278,11 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   } else if (slot >= 0) {
     produce([&](int) {});
   } else {
-    for (int t = 0; t < ntiles; ++t) tile_barrier();       // a wave that neither chains nor produces (1024-thread workgroup)
+    for (int t = 0; t < nbar; ++t) tile_barrier();         // a wave that neither chains nor produces (1024-thread workgroup)
   }
   __syncthreads();                                         // the phase's stores (mod, bnd, dterm) are visible to the workgroup
-  if (parity && ntiles > 0 && chain_wave) chain_step(ntiles - 1);
+  if (parity && chain_wave)                                // the blocks the loop above has not added: the last one, or the last two
+    for (int t = max((allprod ? nblocks : nbar) - 1, 0); t < nblocks; ++t) chain_step(t);
   counter = block_sum_int(S, counter);
   inl = block_sum_int(S, inl);
   if (DEFER) {
