@@ -1145,10 +1145,11 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   // buffers of KB tiles in the (idle) tiles of phase A2.
   constexpr int KB = parity && !allprod && !SH::BSUM && SH::NW < 8 ? FL_ICP_BMACRO : 1;
   static_assert(KB == 1 || sizeof(S.prod) >= (size_t)2 * KB * TQ * sizeof(float), "two blocks of KB tiles of terms fit the A2 tiles");
+  // Block 0 is tile 0 alone (the chain starts after one tile, not after KB), block m >= 1 the tiles (m - 1) KB + 1 .. m KB.
   auto dbuf = [&](int t) -> float * {                    // where the terms of tile t go
     if (KB == 1) return S.dtile[t & 1];
-    const int m = t / KB;
-    return (float *)&S.prod[0][0][0] + ((m & 1) * KB + (t - m * KB)) * TQ;
+    const int m = (t + KB - 1) / KB, first = m == 0 ? 0 : (m - 1) * KB + 1;
+    return (float *)&S.prod[0][0][0] + ((m & 1) * KB + (t - first)) * TQ;
   };
   // The phase is one memory round trip + one barrier per tile, so the next tile's (coalesced) loads are issued before this
   // tile is processed.  Two register sets trade roles by unrolling the tile loop twice -- never by moving registers, and
@@ -1211,14 +1212,17 @@ __device__ __forceinline__ float l2dist_phase(SH &S, float *mod, const float *re
   };
   // tile t (block t of KB tiles) is complete in LDS: the chain wave adds it (every lane of the wave enters)
   auto chain_step = [&](int t) {
-    const float *col = dbuf(t * KB);
-    const int rows = min(KB * TQ, n - t * KB * TQ);
+    const int first = KB == 1 || t == 0 ? t : (t - 1) * KB + 1, last = KB == 1 || t == 0 ? t : t * KB;   // the block's tiles
+    const float *col = dbuf(first);
+    const int rows = min((last + 1) * TQ, n) - first * TQ;
     if (SH::BSUM) acc = chain_block_nonneg<SH::CHAIN_NBUF>(col, rows, acc);
     else if (clane == 0) acc = chain_tile<SH::CHAIN_NBUF>(col, rows, acc);
   };
-  const int nblocks = (ntiles + KB - 1) / KB, nbar = KB == 1 ? ntiles : ntiles / KB;   // blocks of tiles; barriers inside the phase
+  // blocks of tiles; barriers inside the phase: behind every COMPLETE block (tile 0, tile KB, tile 2 KB, ...)
+  const int nblocks = KB == 1 ? ntiles : (ntiles > 0 ? (ntiles - 1 + KB - 1) / KB + 1 : 0);
+  const int nbar = KB == 1 ? ntiles : (ntiles > 0 ? (ntiles - 1) / KB + 1 : 0);
   auto block_barrier = [&](int t) {                       // behind tile t: the barrier that closes a block
-    if (KB == 1 || (t + 1) % KB == 0) tile_barrier();
+    if (KB == 1 || t % KB == 0) tile_barrier();
   };
   const bool chain_wave = __builtin_amdgcn_readfirstlane(clane) >= 0;
   // producer loop: `before_barrier(t)` runs behind the rows of tile t (the chain wave's block sum of tile t - 1 when every wave
