@@ -91,8 +91,9 @@
 #define FL_ICP_NBQ 4              // organised search: candidate positions fetched per batch (4 VGPRs each)
 #endif
 #ifndef FL_ICP_NBUF_SMALL
-#define FL_ICP_NBUF_SMALL 2       // 16-row register batches of a chain in the 256-thread kernel (with the split loops 2 / 3 / 4 measure
-                                  // the same 20.8-20.9 ms per 2048 frames: the chains do not wait for their LDS reads either)
+#define FL_ICP_NBUF_SMALL 4       // 16-row register batches of a chain in the 256-thread kernel.  Round 3: 2 / 3 / 4 measured the same; since
+                                  // the dist_mean chain runs over blocks of four tiles (FL_ICP_BMACRO) 2 / 3 / 4 / 6 give 29.5 / 29.2 / 29.1 /
+                                  // 38.1 ms per 4096 frames (6: the batches spill)
 #endif
 #ifndef FL_ICP_BSUM
 #define FL_ICP_BSUM 1             // parity mode: the dist_mean chain (non-negative terms) adds whole blocks exactly (chain_block_nonneg) and falls
