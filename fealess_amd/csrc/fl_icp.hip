@@ -155,7 +155,7 @@
 //   nd     n x f32    organised search, parity mode: squared distance to nn[i] (the search runs ahead of the threshold it is
 //                     compared with, see "Search ahead of the distance chain")
 //   dterm  n x f32    parity mode: the terms of getL2distClouds' dist_mean chain, index order (0 for a dropped pair)
-//   perm   n x i32    organised search: model indices in 16x4-pixel tile order
+//   perm   n x i32    organised search: model indices in 16x4-pixel tile order, column by column inside a tile (build_tile_order)
 //   cell_start / cell_cur   CSR offsets of the x/y cell grid (grid search)
 //   nrm   n x 3 f32   unit normals of the reference cloud, index order (FL_ICP_POINT_TO_PLANE only; 0 = unknown)
 struct IcpWsLayout {
@@ -1609,9 +1609,11 @@ __device__ __forceinline__ void icp_run(SH &S, uint8_t *wsb, const IcpWsLayout &
   // With the 4-byte image a step's staged data is a handful of dwords per lane, so the NEXT step can be prepared -- its
   // windows, its union rectangle, its staging loads issued -- before this step is scanned: the loads' round trip (a third of a
   // step) runs underneath the scan instead of in front of it.  Two prepared-step states trade roles by unrolling the loop
-  // twice (never by moves: see the chain phases); a state always issues ICP_PIPE_NP loads (slots past its rectangle read the
-  // guard behind the image), so the instruction stream between issue and use has no branch that would make the compiler drain
-  // the queue.  Same windows, same candidates, same keys: bit-identical to org_search.
+  // twice (never by moves: see the chain phases).  A state issues its loads in wave-uniform pairs of passes (FL_ICP_PIPE_COND; the
+  // first version always issued ICP_PIPE_NP, slots past the rectangle reading the guard behind the image, for fear that a branch
+  // between issue and use would make the compiler drain the queue: it does not -- the wait in front of the first use is
+  // counted for the shortest path -- and with the column-major tiles seven steps in ten need only two passes).  Same windows,
+  // same candidates, same keys: bit-identical to org_search.
 #ifndef FL_ICP_PIPE
 #define FL_ICP_PIPE 1
 #endif
@@ -2364,7 +2366,8 @@ __device__ __forceinline__ int crop_clouds(SH &S, const IcpArgs &a, const uint16
 }
 
 // The model indices in tile order (FL_ICP_TILE_W x 64 / FL_ICP_TILE_W pixels: 16 x 4) (tile rows alternately left-to-right and right-to-left, so consecutive tiles
-// are neighbours): the 64 queries a wave takes per step then project into a compact window of the reference image.
+// are neighbours; inside a tile column by column: FL_ICP_TILE_COLMAJOR): the 64 queries a wave takes per step then project into a
+// compact window of the reference image.
 // Index k of crop pixel p is idximg[p] (the paired compaction keeps the same pixels of both clouds).
 template <class SH>
 __device__ __forceinline__ void build_tile_order(SH &S, const int *idximg, int cw, int ch, int n, int *perm)
